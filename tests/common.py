@@ -1,0 +1,28 @@
+"""Helpers shared by the CPU and GPU test modules."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def tables_from(fx, prefix: str = "tab_") -> ScenarioTables:
+    return ScenarioTables.from_arrays({k[len(prefix):]: fx[k] for k in fx.files if k.startswith(prefix)})
+
+
+AGENT_CASES = ["agent_ref_mixed", "agent_ref_rr", "agent_ref_pf_nosort", "agent_ref_mt",
+               "agent_scaled_mixed", "agent_scaled_pf_nosort"]
+TRACE_CASES = ["trace_ref_random", "trace_ref_marr", "trace_ref_mapf", "trace_scaled_mapf",
+               "trace_scaled_random", "trace_plumbing"]
+
+# float tolerance between the oracle and the reference's own outputs: both are IEEE double in
+# numpy's operation order, so they agree to rounding of a handful of operations.
+RTOL, ATOL = 1e-12, 1e-12

@@ -1,0 +1,549 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the reference's OWN functions.
+
+Run in the build container only (the reference lives at /root/reference and never
+travels):
+
+    python tests/golden/gen_golden.py
+
+What is imported from the reference: agents/common.py, agents/ib_sched.py,
+agents/marr.py, agents/mapf.py, associations/mult_slice.py, traffics/mult_slice.py.
+Their base classes come from ``sixg_radio_mgmt``, an un-vendored git submodule that is
+empty in the snapshot, so this script installs attribute-holding stand-ins for those
+base classes (constructors that store their arguments, nothing else) and a dummy
+``gymnasium.spaces``.  No reference source text is stored in the fixtures: they hold
+inputs and the outputs the reference functions returned.
+
+Tie handling: the reference calls ``np.argsort`` with the default kind, whose order
+among equal keys depends on the numpy build.  Fixtures flagged
+``stable_argsort=1`` were produced with ``np.argsort`` forced to ``kind="stable"``
+inside the reference modules; tie-free function cases run the reference untouched.
+
+The env core (sixg_radio_mgmt UEs/Buffer) does not exist in the snapshot; closed-loop
+traces use the build's CPU oracle (oracle/ranenv_oracle.c) for it and thereby pin the
+AGENT side end to end; the env-core numbers in them are the build's own regression
+baseline (parity unpinned).
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("RANENV_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+
+# ----------------------------------------------------------------------------------
+# stand-ins for the missing submodule (attribute holders only)
+# ----------------------------------------------------------------------------------
+def install_standins():
+    m = types.ModuleType("sixg_radio_mgmt")
+
+    class MARLCommEnv:  # noqa: D401 - attribute holder
+        pass
+
+    class Agent:
+        def __init__(self, env, max_number_ues, max_number_slices, max_number_basestations,
+                     num_available_rbs, seed=0):
+            self.env = env
+            self.max_number_ues = max_number_ues
+            self.max_number_slices = max_number_slices
+            self.max_number_basestations = max_number_basestations
+            self.num_available_rbs = num_available_rbs
+            self.seed = seed
+
+    class Association:
+        def __init__(self, ues, max_number_ues, max_number_basestations, max_number_slices, rng, root_path=""):
+            self.ues = ues
+            self.max_number_ues = max_number_ues
+            self.max_number_basestations = max_number_basestations
+            self.max_number_slices = max_number_slices
+            self.rng = rng
+            self.root_path = root_path
+
+    class Traffic:
+        def __init__(self, max_number_ues, rng, root_path=""):
+            self.max_number_ues = max_number_ues
+            self.rng = rng
+            self.root_path = root_path
+
+    class Channel:
+        def __init__(self, max_number_ues, max_number_basestations, num_available_rbs, rng,
+                     root_path="", scenario_name=""):
+            self.max_number_ues = max_number_ues
+            self.max_number_basestations = max_number_basestations
+            self.num_available_rbs = num_available_rbs
+            self.rng = rng
+            self.root_path = root_path
+
+    class Mobility:
+        def __init__(self, max_number_ues, rng, root_path=""):
+            self.max_number_ues = max_number_ues
+            self.rng = rng
+
+    class UEs:
+        def __init__(self, max_number_ues, max_buffer_latencies, max_buffer_pkts, pkt_sizes):
+            self.max_number_ues = max_number_ues
+            self.max_buffer_latencies = np.array(max_buffer_latencies)
+            self.max_buffer_pkts = np.array(max_buffer_pkts)
+            self.pkt_sizes = np.array(pkt_sizes)
+
+        def update_ues(self, ue_indexes, max_buffer_latencies, max_buffer_pkts, pkt_sizes):
+            self.max_buffer_latencies[ue_indexes] = max_buffer_latencies
+            self.max_buffer_pkts[ue_indexes] = max_buffer_pkts
+            self.pkt_sizes[ue_indexes] = pkt_sizes
+
+    for k, v in dict(MARLCommEnv=MARLCommEnv, Agent=Agent, Association=Association, Traffic=Traffic,
+                     Channel=Channel, Mobility=Mobility, UEs=UEs).items():
+        setattr(m, k, v)
+    sys.modules["sixg_radio_mgmt"] = m
+    g = types.ModuleType("gymnasium")
+    sp = types.ModuleType("gymnasium.spaces")
+
+    class _Space:
+        def __init__(self, *a, **k):
+            self.args, self.kwargs = a, k
+
+    sp.Box = sp.Dict = sp.Discrete = _Space
+    g.spaces = sp
+    sys.modules["gymnasium"] = g
+    sys.modules["gymnasium.spaces"] = sp
+    if "matplotlib.pylab" not in sys.modules:
+        try:
+            import matplotlib.pylab  # noqa: F401  (agents/mapf.py:6 imports a name from it)
+        except Exception:  # pragma: no cover
+            mp = types.ModuleType("matplotlib"); pl = types.ModuleType("matplotlib.pylab"); pl.f = None
+            sys.modules["matplotlib"] = mp; sys.modules["matplotlib.pylab"] = pl
+    sys.path.insert(0, REF)
+    return m
+
+
+class _StableNumpy:
+    """numpy proxy whose argsort is stable; installed as ``np`` inside reference modules."""
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+    @staticmethod
+    def argsort(a, *args, **kw):
+        kw.setdefault("kind", "stable")
+        return np.argsort(a, *args, **kw)
+
+
+sixg = install_standins()
+from agents import common as ref_common          # noqa: E402
+from agents import ib_sched as ref_ib_sched      # noqa: E402
+from agents.ib_sched import IBSched              # noqa: E402
+from agents.marr import MARR                     # noqa: E402
+from agents.mapf import MAPF                     # noqa: E402
+from associations.mult_slice import MultSliceAssociation  # noqa: E402
+from traffics.mult_slice import MultSliceTraffic          # noqa: E402
+
+from intent_radio_sched_multi_slice_amd.scenario import (  # noqa: E402
+    ScenarioTables, generate_scaled_scenarios)
+from oracle import pyoracle                       # noqa: E402
+from tests.synth import se_tile                   # noqa: E402
+
+META = {"numpy": np.__version__, "reference": "lasseufpa/intent_radio_sched_multi_slice snapshot 2026-03-13"}
+
+
+def set_stable(flag: bool):
+    ref_common.np = _StableNumpy() if flag else np
+    ref_ib_sched.np = _StableNumpy() if flag else np
+
+
+def has_ties(v) -> bool:
+    v = np.asarray(v, dtype=float)
+    v = v[v != 0]
+    return len(np.unique(v)) != len(v)
+
+
+# ----------------------------------------------------------------------------------
+# 1. stateless functions
+# ----------------------------------------------------------------------------------
+def gen_functions():
+    rng = np.random.default_rng(1234)
+    out = {}
+    # round_int_equal_sum, tie-free, reference untouched
+    set_stable(False)
+    vals, tgts, exps = [], [], []
+    for T in (25, 27, 135, 5, 0):
+        for n in range(1, 11):
+            for _ in range(6):
+                v = rng.uniform(0.01, 10.0, n)
+                v[rng.random(n) < 0.2] = 0.0
+                if not np.any(v) or has_ties(v):
+                    continue
+                pad = np.full(10, np.nan); pad[:n] = v
+                vals.append(pad); tgts.append(T)
+                e = np.full(10, -1, dtype=np.int64); e[:n] = ref_common.round_int_equal_sum(v.copy(), T)
+                exps.append(e)
+    out["rie_values"] = np.array(vals); out["rie_target"] = np.array(tgts); out["rie_expected"] = np.array(exps)
+    # round_int_equal_sum with ties, stable rule
+    set_stable(True)
+    vals, tgts, exps = [], [], []
+    for T in (25, 27, 135, 7):
+        for n in range(2, 11):
+            for _ in range(4):
+                v = rng.integers(1, 4, n).astype(float)
+                v[rng.random(n) < 0.2] = 0.0
+                if not np.any(v):
+                    continue
+                pad = np.full(10, np.nan); pad[:n] = v
+                vals.append(pad); tgts.append(T)
+                e = np.full(10, -1, dtype=np.int64); e[:n] = ref_common.round_int_equal_sum(v.copy(), T)
+                exps.append(e)
+    out["rie_tie_values"] = np.array(vals); out["rie_tie_target"] = np.array(tgts)
+    out["rie_tie_expected"] = np.array(exps)
+    # scores_to_rbs: 3..S active, inactive forced to -1 (ib_sched.py:248-255); T in {25,27,135}
+    acts, assocs, tgts, exps, stab = [], [], [], [], []
+    for S in (5, 10):
+        for T in (25, 27, 135):
+            for _ in range(12):
+                n_act = rng.integers(3, S, endpoint=True)
+                assoc = np.zeros(S); assoc[rng.choice(S, n_act, replace=False)] = 1
+                a = rng.uniform(-1, 1, S); a[assoc == 0] = -1
+                kind = rng.integers(0, 4)
+                if kind == 0:
+                    a[assoc == 1] = 1.0            # MARR action: all ties
+                elif kind == 1:
+                    a[:] = -1.0                    # sum(action+1) == 0 branch (common.py:451-454)
+                tie = has_ties(a + 1) or kind == 1
+                set_stable(bool(tie))
+                e = ref_common.scores_to_rbs(a.copy(), T, assoc.copy())
+                pa = np.full(10, np.nan); pa[:S] = a
+                ps = np.full(10, np.nan); ps[:S] = assoc
+                pe = np.full(10, -1, dtype=np.int64); pe[:S] = e
+                acts.append(pa); assocs.append(ps); tgts.append(T); exps.append(pe); stab.append(int(tie))
+    out["s2r_action"] = np.array(acts); out["s2r_assoc"] = np.array(assocs)
+    out["s2r_target"] = np.array(tgts); out["s2r_expected"] = np.array(exps); out["s2r_stable"] = np.array(stab)
+    set_stable(False)
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "functions.npz"), **out)
+    print("functions.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+# ----------------------------------------------------------------------------------
+# 2. association generator + traffic draw order
+# ----------------------------------------------------------------------------------
+def gen_assoc_traffic():
+    out = {}
+    S, U = 5, 25
+    rng = np.random.default_rng(10)                      # gen_assoc_mult_slice.py:14
+    bsa_l, sua_l, types_l, tables = [], [], [], ScenarioTables.empty(10, S, U, 5)
+    for ep in range(10):
+        ues = sixg.UEs(U, np.repeat(100, U), np.repeat(1024, U), np.repeat(100, U))
+        assoc = MultSliceAssociation(ues, U, 1, S, rng, generator_mode=True)
+        bua, bsa, sua, req = assoc.step(np.zeros((1, U)), np.zeros((1, S)), np.zeros((S, U)), {}, 0, ep)
+        bsa_l.append(bsa.copy()); sua_l.append(sua.copy())
+        types_l.append([assoc.slice_types.index(req[f"slice_{s}"]["name"]) if req[f"slice_{s}"] else -1
+                        for s in range(S)])
+        set_stable(True)
+        tables.set_from_reference(ep, bsa, sua, req, True,
+                                  (ues.pkt_sizes, ues.max_buffer_pkts, ues.max_buffer_latencies))
+        srt = IBSched.sort_slices(None, req, sua, S)
+        set_stable(False)
+        assert np.array_equal(srt, tables.sorted_slices[ep])
+    out["assoc_bsa"] = np.array(bsa_l); out["assoc_sua"] = np.array(sua_l); out["assoc_types"] = np.array(types_l)
+    for k, v in tables.arrays().items():
+        out["assoc_tab_" + k] = v
+    # traffic: seeds 10 and 15 (simu.py:203-204), scenario 0 above, 20 TTIs
+    bua, bsa, sua, req = tables.to_reference(0)
+    for seed in (10, 15):
+        tr = MultSliceTraffic(U, np.random.default_rng(seed))
+        out[f"traffic_seed{seed}"] = np.array([tr.step(sua, req, t, 0) for t in range(20)])
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "assoc_traffic.npz"), **out)
+    print("assoc_traffic.npz ok")
+
+
+# ----------------------------------------------------------------------------------
+# reference-side helpers
+# ----------------------------------------------------------------------------------
+def make_env_stub(U, R, bw, tables, idx):
+    env = sixg.MARLCommEnv()
+    env.comm_env = types.SimpleNamespace()
+    env.comm_env.bandwidths = np.array([bw])
+    env.comm_env.num_available_rbs = np.array([R])
+    env.comm_env.ues = sixg.UEs(U, tables.ue_max_age[idx].copy(), tables.ue_max_pkts[idx].copy(),
+                                tables.ue_pkt_size[idx].copy())
+    return env
+
+
+def make_agent(env, S, U, R, G, Us, sort):
+    ag = IBSched(env, U, S, 1, np.array([R]), enable_sort_slices=sort)
+    ag.rbs_per_rbg = G
+    ag.max_number_ues_slice = Us
+    return ag
+
+
+def flat_obs(obs, S):
+    oi = np.asarray(obs["player_0"]["observations"], dtype=float)
+    mi = np.asarray(obs["player_0"]["action_mask"]).astype(np.int8)
+    oa = np.stack([np.asarray(obs[f"player_{s + 1}"]["observations"], dtype=float) for s in range(S)])
+    ma = np.stack([np.asarray(obs[f"player_{s + 1}"]["action_mask"]).astype(np.int8) for s in range(S)])
+    return oi, mi, oa, ma
+
+
+def flat_reward(rw, S):
+    return np.array([rw["player_0"]] + [rw[f"player_{s + 1}"] for s in range(S)], dtype=float)
+
+
+def dense_to_ranges(alloc):
+    a = np.asarray(alloc)[0]
+    cnt = a.sum(axis=1).astype(np.int32)
+    start = np.zeros(a.shape[0], dtype=np.int32)
+    for u in range(a.shape[0]):
+        nz = np.nonzero(a[u])[0]
+        if len(nz):
+            start[u] = nz[0]
+            assert nz[-1] - nz[0] + 1 == len(nz), "reference allocation not contiguous"
+    return start, cnt
+
+
+def raw_dict(tables, idx, se32, occ, lat, sent, dropped, sched):
+    bua, bsa, sua, req = tables.to_reference(idx)
+    return {
+        "slice_req": req, "slice_ue_assoc": sua, "basestation_slice_assoc": bsa,
+        "basestation_ue_assoc": bua,
+        "spectral_efficiencies": se32.astype(np.float64)[None, :, :],
+        "buffer_occupancies": np.asarray(occ, dtype=float), "buffer_latencies": np.asarray(lat, dtype=float),
+        "pkt_effective_thr": np.asarray(sent, dtype=float), "dropped_pkts": np.asarray(dropped, dtype=float),
+        "sched_decision": np.asarray(sched, dtype=float),
+    }
+
+
+def random_action(rng, S, mode):
+    if mode == "ties":
+        sc = rng.choice([-1.0, -0.5, 0.0, 0.5, 1.0], S)
+    else:
+        sc = rng.uniform(-1, 1, S)
+    return sc, rng.integers(0, 3, S)
+
+
+def call_action_format(agent, scores, intra, fixed):
+    act = {"player_0": np.array(scores, dtype=float)}
+    if fixed is None:
+        for s in range(len(intra)):
+            act[f"player_{s + 1}"] = int(intra[s])
+    return agent.action_format(act, fixed_intra=fixed)
+
+
+# ----------------------------------------------------------------------------------
+# 3. agent side on synthetic raw observations
+# ----------------------------------------------------------------------------------
+def gen_agent_sequence(name, S, U, R, G, Us, tables, scen_ids, steps, fixed, sort, seed, bw=100e6):
+    set_stable(True)
+    rng = np.random.default_rng(seed)
+    rec = {k: [] for k in ("scen", "occ", "lat", "sent", "dropped", "rowsum", "obs_inter", "mask_inter",
+                           "obs_intra", "mask_intra", "reward", "drift", "scores", "intra", "rb_start",
+                           "rb_count", "marr", "mapf")}
+    env = make_env_stub(U, R, bw, tables, scen_ids[0])
+    agent = make_agent(env, S, U, R, G, Us, sort)
+    marr = MARR(env, U, S, 1, np.array([R])); marr.fake_agent = agent
+    mapf = MAPF(env, U, S, 1, np.array([R])); mapf.fake_agent = agent
+    sched = np.zeros((1, U, R))
+    per = steps // len(scen_ids)
+    for t in range(steps):
+        idx = scen_ids[min(t // per, len(scen_ids) - 1)]
+        env.comm_env.ues = sixg.UEs(U, tables.ue_max_age[idx].copy(), tables.ue_max_pkts[idx].copy(),
+                                    tables.ue_pkt_size[idx].copy())
+        se32 = se_tile(seed, t, U, R, low_se_every=7)
+        occ = np.zeros(U); lat = np.zeros(U); sent = np.zeros(U); dropped = np.zeros(U)
+        regime = (t // 5) % 4           # 0 mixed, 1 all buffers empty, 2 no history, 3 heavy loss
+        for u in range(U):
+            s = tables.ue_slice[idx, u]
+            if s < 0:
+                continue
+            bmax = int(tables.ue_max_pkts[idx, u]); amax = int(tables.ue_max_age[idx, u])
+            msg = int(tables.ue_pkt_size[idx, u])
+            if regime != 1 and rng.random() > 0.3:
+                occ[u] = rng.integers(1, bmax, endpoint=True) / bmax
+                lat[u] = rng.uniform(0, amax)
+            req_pkts = max(1, int(tables.slice_traffic[idx, s] * 1e6 / msg))
+            if regime != 2 and rng.random() > 0.2:
+                sent[u] = rng.integers(0, 3 * req_pkts)
+            if (regime == 3 and rng.random() > 0.3) or rng.random() > 0.8:
+                dropped[u] = rng.integers(1, 1 + req_pkts)
+        raw = raw_dict(tables, idx, se32, occ, lat, sent, dropped, sched)
+        obs = agent.obs_space_format(raw)
+        drift = ref_common.intent_drift_calc(agent.last_unformatted_obs, Us, agent.intent_overfulfillment_rate)
+        rw = agent.calculate_reward(obs)
+        oi, mi, oa, ma = flat_obs(obs, S)
+        a_marr = marr.step(None).astype(float)
+        a_mapf = np.asarray(mapf.step(None), dtype=float)
+        mode = ("ties", "rand", "marr", "mapf")[t % 4]
+        if mode == "marr":
+            sc, ic = a_marr.copy(), rng.integers(0, 3, S)
+        elif mode == "mapf":
+            sc, ic = a_mapf.copy(), rng.integers(0, 3, S)
+        else:
+            sc, ic = random_action(rng, S, mode)
+        if fixed is not None:
+            ic = np.full(S, {"rr": 0, "pf": 1, "mt": 2}[fixed])
+        sched = call_action_format(agent, sc, ic, fixed)
+        st, ct = dense_to_ranges(sched)
+        for k, v in (("scen", idx), ("occ", occ), ("lat", lat), ("sent", sent), ("dropped", dropped),
+                     ("rowsum", raw["sched_decision"][0].sum(axis=1)), ("obs_inter", oi), ("mask_inter", mi),
+                     ("obs_intra", oa), ("mask_intra", ma), ("reward", flat_reward(rw, S)), ("drift", drift),
+                     ("scores", sc), ("intra", ic), ("rb_start", st), ("rb_count", ct), ("marr", a_marr),
+                     ("mapf", a_mapf)):
+            rec[k].append(np.array(v))
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update({"tab_" + k: v for k, v in tables.arrays().items()})
+    out["cfg"] = np.array([S, U, R, G, Us, seed, int(sort), steps])
+    out["bw"] = np.array(bw)
+    out["stable_argsort"] = np.array(1)
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    set_stable(False)
+    print(name, "steps", steps)
+
+
+# ----------------------------------------------------------------------------------
+# 4. closed loop: build's CPU env core (oracle) + the reference's agent code
+# ----------------------------------------------------------------------------------
+def gen_trace(name, S, U, R, G, Us, tables, scen_ids, steps_per_ep, policy, sort, seed, bw=100e6,
+              max_age_cap=400, plumbing=False):
+    set_stable(True)
+    rng = np.random.default_rng(seed)
+    cfg = pyoracle.make_cfg(S, U, R, G, Us, bandwidth_hz=bw, max_age_cap=max_age_cap, max_steps=steps_per_ep)
+    core = pyoracle.OracleEnv(cfg)
+    env = make_env_stub(U, R, bw, tables, scen_ids[0])
+    agent = make_agent(env, S, U, R, G, Us, sort)
+    marr = MARR(env, U, S, 1, np.array([R])); marr.fake_agent = agent
+    mapf = MAPF(env, U, S, 1, np.array([R])); mapf.fake_agent = agent
+    keys = ("scores", "intra", "traffic", "rb_start", "rb_count", "pkt_incoming", "pkt_throughputs",
+            "pkt_effective_thr", "dropped_pkts", "buffer_occupancies", "buffer_latencies", "obs_inter",
+            "mask_inter", "obs_intra", "mask_intra", "reward")
+    rec = {k: [] for k in keys}
+    reset_obs = []
+    fixed = {"marr": "rr", "mapf": "pf", "random": None, "mt": "mt"}[policy]
+    t_global = 0
+    for ep, idx in enumerate(scen_ids):
+        bua, bsa, sua, req = tables.to_reference(idx)
+        env.comm_env.ues = sixg.UEs(U, tables.ue_max_age[idx].copy(), tables.ue_max_pkts[idx].copy(),
+                                    tables.ue_pkt_size[idx].copy())
+        traffic_gen = MultSliceTraffic(U, np.random.default_rng(seed * 100 + ep))
+        core.set_scenario(tables, idx)
+        # plumbing: FixedSE (channels/fixed_se.py:26) and SimpleTraffic (traffics/simple.py:22)
+        get_se = (lambda t: np.full((U, R), 2.0, dtype=np.float32)) if plumbing else \
+            (lambda t: se_tile(seed + ep, t, U, R))
+        se0 = get_se(0)
+        core.reset(se0)
+        raw = raw_dict(tables, idx, se0, np.zeros(U), np.zeros(U), np.zeros(U), np.zeros(U), np.zeros((1, U, R)))
+        obs = agent.obs_space_format(raw)             # CommunicationEnv.reset returns the formatted obs
+        reset_obs.append(np.concatenate([flat_obs(obs, S)[0], flat_obs(obs, S)[2].ravel()]))
+        for t in range(steps_per_ep):
+            if policy == "marr":
+                sc, ic = marr.step(None).astype(float), np.zeros(S, dtype=int)
+            elif policy == "mapf":
+                sc, ic = np.asarray(mapf.step(None), dtype=float), np.ones(S, dtype=int)
+            elif policy == "mt":
+                sc, ic = rng.uniform(-1, 1, S), np.full(S, 2)
+            else:
+                sc, ic = random_action(rng, S, "ties" if t % 3 == 0 else "rand")
+            sched = call_action_format(agent, sc, ic, fixed)
+            st, ct = dense_to_ranges(sched)
+            se32 = get_se(t)
+            traffic = np.ones(U) * 4 if plumbing else traffic_gen.step(sua, req, t, ep)
+            if plumbing and t % 7 == 3:
+                traffic = rng.poisson(6, U).astype(float)
+            if t % 11 == 5:
+                traffic = traffic * 6.0              # bursts: fill buffers, force drops
+            core.core_step(sched[0].astype(np.uint8), se32, traffic)
+            m = core.raw()
+            raw = raw_dict(tables, idx, se32, m["buffer_occupancies"], m["buffer_latencies"],
+                           m["pkt_effective_thr"], m["dropped_pkts"], sched)
+            obs = agent.obs_space_format(raw)
+            rw = agent.calculate_reward(obs)
+            oi, mi, oa, ma = flat_obs(obs, S)
+            for k, v in (("scores", sc), ("intra", ic), ("traffic", traffic), ("rb_start", st), ("rb_count", ct),
+                         ("obs_inter", oi), ("mask_inter", mi), ("obs_intra", oa), ("mask_intra", ma),
+                         ("reward", flat_reward(rw, S))):
+                rec[k].append(np.array(v))
+            for k in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts",
+                      "buffer_occupancies", "buffer_latencies"):
+                rec[k].append(m[k].copy())
+            t_global += 1
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["reset_obs"] = np.array(reset_obs)
+    out["scen_ids"] = np.array(scen_ids)
+    out.update({"tab_" + k: v for k, v in tables.arrays().items()})
+    out["cfg"] = np.array([S, U, R, G, Us, seed, int(sort), steps_per_ep, max_age_cap, int(plumbing)])
+    out["bw"] = np.array(bw)
+    out["stable_argsort"] = np.array(1)
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    set_stable(False)
+    print(name, "episodes", len(scen_ids), "x", steps_per_ep)
+
+
+def ref_tables(n, seed, S=5, U=25, Us=5, sort=True):
+    """Scenarios from the reference's own generator (associations/mult_slice.py:359-423)."""
+    rng = np.random.default_rng(seed)
+    t = ScenarioTables.empty(n, S, U, Us)
+    set_stable(True)
+    for i in range(n):
+        ues = sixg.UEs(U, np.repeat(100, U), np.repeat(1024, U), np.repeat(100, U))
+        assoc = MultSliceAssociation(ues, U, 1, S, rng, generator_mode=True)
+        assoc.max_number_slices = S
+        bua, bsa, sua, req = assoc.step(np.zeros((1, U)), np.zeros((1, S)), np.zeros((S, U)), {}, 0, i)
+        t.set_from_reference(i, bsa, sua, req, sort,
+                             (ues.pkt_sizes, ues.max_buffer_pkts, ues.max_buffer_latencies))
+    set_stable(False)
+    return t
+
+
+def plumbing_tables():
+    """BASELINE config 1: 4 UEs, 25 RBs; slice intents of associations/simple_slice.py:46-105."""
+    t = ScenarioTables.empty(1, 2, 4, 4)
+    req = {
+        "slice_0": {"name": "a", "priority": 1, "parameters": {
+            "par1": {"name": "reliability", "value": 99.0, "operator": np.greater_equal},
+            "par2": {"name": "latency", "value": 20, "operator": np.less_equal},
+            "par3": {"name": "throughput", "value": 1, "operator": np.greater_equal}},
+            "ues": {"buffer_size": 10, "buffer_latency": 10, "message_size": 1, "traffic": 2}},
+        "slice_1": {"name": "b", "priority": 0, "parameters": {
+            "par1": {"name": "reliability", "value": 1.0, "operator": np.greater_equal},
+            "par2": {"name": "latency", "value": 20, "operator": np.less_equal}},
+            "ues": {"buffer_size": 10, "buffer_latency": 10, "message_size": 1, "traffic": 2}},
+    }
+    sua = np.zeros((2, 4)); sua[0, [0, 2]] = 1; sua[1, [1, 3]] = 1
+    t.set_from_reference(0, np.ones((1, 2)), sua, req, True)
+    return t
+
+
+def main():
+    os.makedirs(HERE, exist_ok=True)
+    gen_functions()
+    gen_assoc_traffic()
+    ref5 = ref_tables(6, seed=10)
+    ref5_nosort = ref_tables(6, seed=10, sort=False)
+    big = generate_scaled_scenarios(4, seed=10)
+    big_nosort = generate_scaled_scenarios(4, seed=10, enable_sort_slices=False)
+    gen_agent_sequence("agent_ref_mixed", 5, 25, 135, 5, 5, ref5, [0, 1], 40, None, True, seed=101)
+    gen_agent_sequence("agent_ref_rr", 5, 25, 135, 5, 5, ref5, [2], 24, "rr", True, seed=102)
+    gen_agent_sequence("agent_ref_pf_nosort", 5, 25, 135, 5, 5, ref5_nosort, [3], 24, "pf", False, seed=103)
+    gen_agent_sequence("agent_ref_mt", 5, 25, 135, 5, 5, ref5, [4], 24, "mt", True, seed=104)
+    gen_agent_sequence("agent_scaled_mixed", 10, 100, 135, 1, 10, big, [0, 1], 32, None, True, seed=105)
+    gen_agent_sequence("agent_scaled_pf_nosort", 10, 100, 135, 1, 10, big_nosort, [2], 20, "pf", False, seed=106)
+    gen_trace("trace_ref_random", 5, 25, 135, 5, 5, ref5, [0, 1], 30, "random", True, seed=201)
+    gen_trace("trace_ref_marr", 5, 25, 135, 5, 5, ref5_nosort, [2, 3], 30, "marr", False, seed=202)
+    gen_trace("trace_ref_mapf", 5, 25, 135, 5, 5, ref5_nosort, [4, 5], 30, "mapf", False, seed=203)
+    gen_trace("trace_scaled_mapf", 10, 100, 135, 1, 10, big_nosort, [0, 1], 26, "mapf", False, seed=204)
+    gen_trace("trace_scaled_random", 10, 100, 135, 1, 10, big, [2, 3], 26, "random", True, seed=205)
+    gen_trace("trace_plumbing", 2, 4, 25, 1, 4, plumbing_tables(), [0], 60, "random", True, seed=206, bw=25.0,
+              max_age_cap=16, plumbing=True)
+
+
+if __name__ == "__main__":
+    main()
