@@ -1,0 +1,206 @@
+/*
+ * ranenv.h -- C ABI of the MI355X-native batched RAN-slicing environment step.
+ *
+ * One handle = B independent environments resident in the HBM of one GPU.  The library
+ * (libranenv_hip.so, built from intent_radio_sched_multi_slice_amd/csrc/ranenv.hip for
+ * gfx950) replaces, for the per-TTI hot path only, what the reference does in Python:
+ *
+ *   reference interface (lasseufpa/intent_radio_sched_multi_slice)      entry point here
+ *   -----------------------------------------------------------------   -------------------
+ *   MARLCommEnv(...) construction                   simu.py:348-362     ranenv_create
+ *   association.step / update_ues  associations/mult_slice.py:350-488   ranenv_load_scenarios,
+ *                                                                       ranenv_set_episodes
+ *   channel.step  (SE tile per TTI)     channels/quadriga.py:38-76      ranenv_bind_se_pool
+ *   traffic.step  (offered bits)        traffics/mult_slice.py:15-34    ranenv_bind_traffic_pool
+ *   env.reset(seed, options)                        simu.py:547-554     ranenv_reset
+ *   env.step(action):                               simu.py:559         ranenv_step
+ *     IBSched.action_format            agents/ib_sched.py:223-349
+ *     UEs.step / Buffer (sixg_radio_mgmt, un-vendored submodule)
+ *     IBSched.obs_space_format         agents/ib_sched.py:63-204
+ *     IBSched.calculate_reward         agents/ib_sched.py:206-221
+ *   env.step with a caller-made sched_decision (any agent's
+ *     action_format callback, simu.py:405-411)                          ranenv_step_dense
+ *   MARR.step / MAPF.step   agents/marr.py:40-47, agents/mapf.py:41-111 ranenv_set_policy
+ *   raw observation dict fields         agents/ib_sched.py:78-181       ranenv_get_views
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RANENV_E_* code; the message is
+ *     available from ranenv_last_error(handle) (handle may be NULL for create failures).
+ *     No exception crosses this boundary.
+ *   - "dev" pointers are device pointers owned by the caller (e.g. torch tensors); "host"
+ *     pointers are ordinary host memory, copied before the call returns.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls on one
+ *     handle must be serialised by the caller; work is enqueued, not synchronised.
+ *   - there is no CPU fallback: if no gfx950 device/kernel image is usable the calls fail.
+ */
+#ifndef RANENV_H
+#define RANENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RANENV_ABI_VERSION 1
+
+enum {
+    RANENV_OK = 0,
+    RANENV_E_INVALID = -1,   /* bad argument / unsupported size               */
+    RANENV_E_HIP = -2,       /* a HIP runtime call failed                     */
+    RANENV_E_STATE = -3,     /* call order (e.g. step before scenarios/pools) */
+    RANENV_E_NOMEM = -4
+};
+
+enum { RANENV_POLICY_EXTERNAL = 0, RANENV_POLICY_MARR = 1, RANENV_POLICY_MAPF = 2 };
+enum { RANENV_INTRA_RR = 0, RANENV_INTRA_PF = 1, RANENV_INTRA_MT = 2, RANENV_INTRA_PER_SLICE = 255 };
+enum { RANENV_METRIC_THROUGHPUT = 0, RANENV_METRIC_RELIABILITY = 1, RANENV_METRIC_LATENCY = 2 };
+enum { RANENV_OP_GE = 0, RANENV_OP_LE = 1, RANENV_OP_EQ = 2, RANENV_OP_GT = 3, RANENV_OP_LT = 4 };
+
+/* flags */
+#define RANENV_F_CLEAR_HISTORY_ON_RESET 0x1 /* default off: the reference never clears the
+                                               10-TTI window (agents/ib_sched.py:51)      */
+#define RANENV_F_NO_RAW_OUTPUT          0x2 /* skip pkt_incoming / pkt_throughputs stores  */
+
+typedef struct ranenv *ranenv_handle;
+
+typedef struct {
+    int32_t abi_version;   /* RANENV_ABI_VERSION                                        */
+    int32_t device;        /* HIP device ordinal                                        */
+    int32_t batch;         /* B   environments on this device                           */
+    int32_t n_slices;      /* S   max_number_slices          (env_config/mult_slice.yml:13) */
+    int32_t n_ues;         /* U   max_number_ues             (:14)                      */
+    int32_t n_rbs;         /* R   num_available_rbs[0]       (:5)                       */
+    int32_t rbs_per_rbg;   /* G   IBSched.rbs_per_rbg        (agents/ib_sched.py:56)    */
+    int32_t max_ues_slice; /* Us  IBSched.max_number_ues_slice (:50)                    */
+    int32_t hist_depth;    /* max_obs_memory = 10            (:49)                      */
+    int32_t max_age_cap;   /* largest buffer_latency a scenario may carry (<= 400 in
+                              associations/mult_slice.py:225)                           */
+    int32_t max_steps;     /* max_number_steps               (env_config/mult_slice.yml:10) */
+    int32_t n_scenarios;   /* rows of the scenario pool                                 */
+    int32_t flags;         /* RANENV_F_*                                                */
+    int32_t reserved;
+    double  bandwidth_hz;  /* bandwidths[0]                  (env_config/mult_slice.yml:2)  */
+    double  overfulfill;   /* intent_overfulfillment_rate = 0.2 (agents/ib_sched.py:53) */
+    double  norm_traffic;  /* 120.0 (agents/ib_sched.py:166)                            */
+    double  norm_ues;      /* 5.0   (:167)                                              */
+    double  norm_se;       /* 40.0  (:168)                                              */
+} ranenv_config;
+
+/* Scenario pool rows, host pointers, row-major [count][...]; same content as the
+ * reference's (basestation_slice_assoc, slice_ue_assoc, slice_req) triple and the per-UE
+ * buffer parameters pushed by update_ues (associations/mult_slice.py:468-488). */
+typedef struct {
+    const int32_t *slice_active;         /* [n][S]                                  */
+    const int32_t *slice_has_req;        /* [n][S]                                  */
+    const int32_t *slice_nues;           /* [n][S]                                  */
+    const int32_t *slice_ues;            /* [n][S][Us] ascending UE ids, -1 padded  */
+    const double  *slice_priority;       /* [n][S]                                  */
+    const double  *slice_traffic;        /* [n][S] Mbps                             */
+    const int32_t *slice_buffer_size;    /* [n][S] packets                          */
+    const int32_t *slice_buffer_latency; /* [n][S] TTIs                             */
+    const int32_t *slice_message_size;   /* [n][S] bits                             */
+    const int32_t *slice_nparams;        /* [n][S] 0..3                             */
+    const int32_t *param_metric;         /* [n][S][3] RANENV_METRIC_*               */
+    const int32_t *param_op;             /* [n][S][3] RANENV_OP_*                   */
+    const double  *param_value;          /* [n][S][3]                               */
+    const int32_t *sorted_slices;        /* [n][S] IBSched.sorted_slices            */
+    const int32_t *ue_slice;             /* [n][U] -1 = idle                        */
+    const int32_t *ue_pos;               /* [n][U] position in its slice            */
+    const int32_t *ue_pkt_size;          /* [n][U]                                  */
+    const int32_t *ue_max_pkts;          /* [n][U]                                  */
+    const int32_t *ue_max_age;           /* [n][U]                                  */
+} ranenv_scenario_tables;
+
+/* Which scenario / channel trace / traffic trace an env replays during its episode
+ * (QuadrigaChannel.choose_episode channels/quadriga.py:78-87,
+ *  MultSliceAssociation.choose_episode associations/mult_slice.py:444-452).
+ * Tile used at TTI t: se_base + (se_offset + t) % se_len; same for traffic rows. */
+typedef struct {
+    int32_t scenario;
+    int32_t se_len;
+    int64_t se_base;
+    int32_t se_offset;
+    int32_t trf_len;
+    int64_t trf_base;
+    int32_t trf_offset;
+    int32_t reserved;
+} ranenv_episode;
+
+/* Device-side views for raw-observation fields and state (all owned by the handle). */
+typedef struct {
+    int32_t *pkt_incoming;      /* [B][U] floor(traffic / pkt_size)                        */
+    int32_t *pkt_throughputs;   /* [B][U] capacity in packets                              */
+    int32_t *pkt_effective_thr; /* [B][U] packets sent this TTI                            */
+    int32_t *dropped_pkts;      /* [B][U]                                                  */
+    int32_t *queue_pkts;        /* [B][U] buffer_occupancies = queue_pkts / max_buffer_pkts */
+    int64_t *queue_age_sum;     /* [B][U] buffer_latencies  = queue_age_sum / queue_pkts   */
+    int32_t *rb_start;          /* [B][U] sched_decision[u] is ones on [rb_start, +rb_count) */
+    int32_t *rb_count;          /* [B][U]                                                  */
+    double  *se_mean;           /* [B][U] mean SE over RBs of the last tile                */
+    int64_t *win_sent;          /* [B][U] sum of pkt_effective_thr over the <=10-TTI window */
+    int64_t *win_dropped;       /* [B][U]                                                  */
+    int32_t *step_number;       /* [B]                                                     */
+    int32_t *hist_len;          /* [B]    len(IBSched.last_unformatted_obs)                */
+    int8_t  *mask_inter;        /* [B][S]     player_0 action_mask                         */
+    int8_t  *mask_intra;        /* [B][S][Us] player_{s+1} action_mask                     */
+    double  *policy_scores;     /* [B][S] inter-slice scores used by the last step         */
+} ranenv_views;
+
+const char *ranenv_last_error(ranenv_handle h);
+int ranenv_abi_version(void);
+
+int ranenv_create(const ranenv_config *cfg, ranenv_handle *out);
+int ranenv_destroy(ranenv_handle h);
+
+/* Copy `count` scenario rows (host) into the pool at rows [first, first+count). */
+int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count,
+                          const ranenv_scenario_tables *host_tables, void *stream);
+
+/* SE pool: float32 tiles of U*R values (row u = UE u, RB-contiguous), tile i at
+ * dev + i*tile_stride floats; tile_stride >= U*R and a multiple of 4. */
+int ranenv_bind_se_pool(ranenv_handle h, const float *dev_pool, int64_t n_tiles, int64_t tile_stride);
+/* Traffic pool: int32 offered bits, row i = [U] at dev + i*U. */
+int ranenv_bind_traffic_pool(ranenv_handle h, const int32_t *dev_pool, int64_t n_rows);
+
+/* Per-env episode descriptors, host pointer [B]. */
+int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *host_episodes, void *stream);
+
+/* Inter-slice policy computed on the device when the step gets no scores, and the
+ * intra-slice scheduler (RANENV_INTRA_PER_SLICE = take it from the step's intra_choice). */
+int ranenv_set_policy(ranenv_handle h, int32_t policy, int32_t fixed_intra);
+
+/* CommunicationEnv.reset for the envs with env_mask[b] != 0 (NULL = all): fresh buffers,
+ * step 0, observation of the zero raw state with the episode's first SE tile.
+ * Outputs may be NULL. dev_se_tiles: [B][U*R] explicit tiles or NULL to use the pool. */
+int ranenv_reset(ranenv_handle h, const uint8_t *dev_env_mask, const float *dev_se_tiles,
+                 float *dev_obs_inter /* [B][S*10] */, float *dev_obs_intra /* [B][S][2*Us+9] */,
+                 double *dev_reward /* [B][S+1] */, void *stream);
+
+/* One TTI for every env.
+ *   dev_inter_scores [B][S] double  action["player_0"]; NULL = device policy
+ *   dev_intra_choice [B][S] uint8   action["player_{s+1}"]; NULL = fixed_intra
+ *   dev_traffic_bits [B][U] double  traffic.step() output; NULL = traffic pool
+ *   dev_se_tiles     [B][U*R] float channel.step() output; NULL = SE pool
+ *   outputs: obs (float32), reward (double, [0] = player_0), done (uint8: step == max_steps) */
+int ranenv_step(ranenv_handle h, const double *dev_inter_scores, const uint8_t *dev_intra_choice,
+                const double *dev_traffic_bits, const float *dev_se_tiles,
+                float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
+                void *stream);
+
+/* Same TTI but with a caller-made dense sched_decision [B][U][R] uint8 (any 0/1 pattern),
+ * as an agent's own action_format callback produces it. */
+int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
+                      const double *dev_traffic_bits, const float *dev_se_tiles,
+                      float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
+                      void *stream);
+
+int ranenv_get_views(ranenv_handle h, ranenv_views *out);
+
+/* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
+int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANENV_H */

@@ -1,0 +1,253 @@
+"""BatchedRanEnv: B independent RAN-slicing environments stepped by one HIP launch.
+
+Host side of the C ABI in include/ranenv.h.  PyTorch is plumbing here (device memory,
+streams); every number is produced by the gfx950 kernels in csrc/ranenv.hip.
+
+gymnasium-style surface, batched (reference: ``env.reset`` / ``env.step`` simu.py:547-566):
+
+    env = BatchedRanEnv(batch=4096, n_slices=10, n_ues=100, n_rbs=135, rbs_per_rbg=1,
+                        max_ues_slice=10, n_scenarios=200)
+    env.load_scenarios(tables)                     # association + slice intents
+    env.bind_se_pool(se)                           # float32 [tiles, R, U] on the GPU
+    env.bind_traffic_pool(bits)                    # int32   [rows, U]    on the GPU
+    env.set_episodes(scenario=..., se_base=..., se_len=..., trf_base=..., trf_len=...)
+    obs = env.reset()
+    obs, reward, done = env.step(inter_scores, intra_choice)   # or env.step() with a device policy
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, INTRA_MT, INTRA_PER_SLICE, INTRA_PF, INTRA_RR,
+                   POLICY_EXTERNAL, POLICY_MAPF, POLICY_MARR, RanEnvError)
+from .scenario import MAX_AGE_CAP_DEFAULT, ScenarioTables
+
+_TORCH_DT = {"i1": torch.int8, "i4": torch.int32, "i8": torch.int64, "f8": torch.float64}
+
+
+class _DevArray:
+    """Zero-copy window on handle-owned device memory (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(x) for x in shape), "typestr": "<" + typestr if typestr != "i1" else "|i1",
+            "data": (int(ptr), False), "version": 2, "strides": None,
+        }
+        self._owner = owner
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedRanEnv:
+    def __init__(self, batch: int, n_slices: int, n_ues: int, n_rbs: int, rbs_per_rbg: int = 1,
+                 max_ues_slice: Optional[int] = None, n_scenarios: int = 1, bandwidth_hz: float = 100e6,
+                 max_steps: int = 1000, hist_depth: int = 10, max_age_cap: int = MAX_AGE_CAP_DEFAULT,
+                 overfulfill: float = 0.2, norm_traffic: float = 120.0, norm_ues: float = 5.0,
+                 norm_se: float = 40.0, device: Optional[torch.device] = None, flags: int = 0):
+        if not torch.cuda.is_available():
+            raise RanEnvError("BatchedRanEnv needs a ROCm GPU (there is no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise RanEnvError(f"device must be a GPU, got {self.device}")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        self.B, self.S, self.U, self.R = int(batch), int(n_slices), int(n_ues), int(n_rbs)
+        self.G = int(rbs_per_rbg)
+        self.Us = int(max_ues_slice if max_ues_slice is not None else max(1, n_ues // n_slices))
+        self.W = 2 * self.Us + 9
+        self.max_steps, self.hist_depth, self.max_age_cap = int(max_steps), int(hist_depth), int(max_age_cap)
+        self.bandwidth_hz = float(bandwidth_hz)
+        self.n_scenarios = int(n_scenarios)
+        self._lib = _lib.load()
+        cfg = _lib.Config(_lib.ABI_VERSION, dev_index, self.B, self.S, self.U, self.R, self.G, self.Us,
+                          self.hist_depth, self.max_age_cap, self.max_steps, self.n_scenarios, int(flags), 0,
+                          self.bandwidth_hz, overfulfill, norm_traffic, norm_ues, norm_se)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            st = self._lib.ranenv_create(C.byref(cfg), C.byref(self._h))
+        if st != 0:
+            msg = self._lib.ranenv_last_error(None)
+            raise RanEnvError(f"ranenv_create failed ({st}): {msg.decode() if msg else ''}")
+        self._keep: Dict[str, object] = {}
+        self._views: Optional[Dict[str, torch.Tensor]] = None
+        B, S = self.B, self.S
+        dev = self.device
+        self.obs_inter = torch.zeros((B, S * 10), dtype=torch.float32, device=dev)
+        self.obs_intra = torch.zeros((B, S, self.W), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros((B, S + 1), dtype=torch.float64, device=dev)
+        self.done = torch.zeros((B,), dtype=torch.uint8, device=dev)
+        self.tables: Optional[ScenarioTables] = None
+        self.episodes: Optional[np.ndarray] = None
+
+    # ------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.ranenv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status: int, what: str):
+        _lib.check(self._lib, self._h, status, what)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype, shape, name):
+        if x is None:
+            return None
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.array(x, copy=True))
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise RanEnvError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    # ------------------------------------------------------------------------------------------
+    def load_scenarios(self, tables: ScenarioTables, first: int = 0):
+        """Association + slice intents (associations/mult_slice.py:350-488) into the pool."""
+        if (tables.n_slices, tables.n_ues, tables.max_ues_slice) != (self.S, self.U, self.Us):
+            raise RanEnvError("scenario tables do not match the env sizes")
+        tables.validate(self.max_age_cap, self.R, self.bandwidth_hz)
+        ct = _lib.ScenarioTablesC()
+        keep = []
+        for name in _lib.SCENARIO_FIELDS:
+            dt = np.float64 if name in _lib.SCENARIO_F64 else np.int32
+            a = np.ascontiguousarray(getattr(tables, name), dtype=dt)
+            keep.append(a)
+            setattr(ct, name, a.ctypes.data)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_load_scenarios(self._h, int(first), tables.n_scenarios, C.byref(ct),
+                                                         self._stream()), "ranenv_load_scenarios")
+        if first == 0 and tables.n_scenarios == self.n_scenarios:
+            self.tables = tables
+
+    def bind_se_pool(self, se_pool: torch.Tensor):
+        """float32 [n_tiles, R, U] (RB-major tiles) resident on this GPU."""
+        if se_pool.dtype != torch.float32 or se_pool.device != self.device or not se_pool.is_contiguous():
+            raise RanEnvError("SE pool must be a contiguous float32 tensor on the env's GPU")
+        if se_pool.dim() != 3 or se_pool.shape[1] != self.R or se_pool.shape[2] != self.U:
+            raise RanEnvError(f"SE pool must be [tiles, R={self.R}, U={self.U}], got {tuple(se_pool.shape)}")
+        self._keep["se_pool"] = se_pool
+        self._check(self._lib.ranenv_bind_se_pool(self._h, _ptr(se_pool), se_pool.shape[0], self.R * self.U),
+                    "ranenv_bind_se_pool")
+
+    def bind_traffic_pool(self, traffic_pool: torch.Tensor):
+        """int32 [rows, U] offered bits per UE and TTI (traffics/mult_slice.py:26-32)."""
+        if traffic_pool.dtype != torch.int32 or traffic_pool.device != self.device or not traffic_pool.is_contiguous():
+            raise RanEnvError("traffic pool must be a contiguous int32 tensor on the env's GPU")
+        if traffic_pool.dim() != 2 or traffic_pool.shape[1] != self.U:
+            raise RanEnvError(f"traffic pool must be [rows, U={self.U}]")
+        self._keep["trf_pool"] = traffic_pool
+        self._check(self._lib.ranenv_bind_traffic_pool(self._h, _ptr(traffic_pool), traffic_pool.shape[0]),
+                    "ranenv_bind_traffic_pool")
+
+    def set_episodes(self, scenario, se_base=0, se_len=1, se_offset=0, trf_base=0, trf_len=1, trf_offset=0):
+        """Which scenario / channel trace / traffic trace each env replays (arrays of [B] or scalars)."""
+        eps = np.zeros(self.B, dtype=[("scenario", "<i4"), ("se_len", "<i4"), ("se_base", "<i8"),
+                                      ("se_offset", "<i4"), ("trf_len", "<i4"), ("trf_base", "<i8"),
+                                      ("trf_offset", "<i4"), ("reserved", "<i4")])
+        assert eps.dtype.itemsize == C.sizeof(_lib.Episode)
+        for k, v in (("scenario", scenario), ("se_len", se_len), ("se_base", se_base), ("se_offset", se_offset),
+                     ("trf_len", trf_len), ("trf_base", trf_base), ("trf_offset", trf_offset)):
+            eps[k] = np.broadcast_to(np.asarray(v), (self.B,))
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_episodes(self._h, C.c_void_p(eps.ctypes.data), self._stream()),
+                        "ranenv_set_episodes")
+        self.episodes = eps
+
+    def set_policy(self, policy: int = POLICY_EXTERNAL, fixed_intra: int = INTRA_PER_SLICE):
+        self._check(self._lib.ranenv_set_policy(self._h, int(policy), int(fixed_intra)), "ranenv_set_policy")
+
+    # ------------------------------------------------------------------------------------------
+    def _obs(self):
+        return {"obs_inter": self.obs_inter, "obs_intra": self.obs_intra}
+
+    def reset(self, env_mask=None, se_tiles=None):
+        """CommunicationEnv.reset for the masked envs (all when None); returns the formatted obs."""
+        m = self._dev(env_mask, torch.uint8, (self.B,), "env_mask")
+        se = self._dev(se_tiles, torch.float32, (self.B, self.R, self.U), "se_tiles")
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_reset(self._h, _ptr(m), _ptr(se), _ptr(self.obs_inter),
+                                                _ptr(self.obs_intra), _ptr(self.reward), self._stream()),
+                        "ranenv_reset")
+        self._keep["last_inputs"] = (m, se)
+        return self._obs()
+
+    def step(self, inter_scores=None, intra_choice=None, traffic_bits=None, se_tiles=None):
+        """One TTI for all envs.  Returns (obs, reward [B,S+1] float64, done [B] uint8)."""
+        sc = self._dev(inter_scores, torch.float64, (self.B, self.S), "inter_scores")
+        ic = self._dev(intra_choice, torch.uint8, (self.B, self.S), "intra_choice")
+        tr = self._dev(traffic_bits, torch.float64, (self.B, self.U), "traffic_bits")
+        se = self._dev(se_tiles, torch.float32, (self.B, self.R, self.U), "se_tiles")
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_step(self._h, _ptr(sc), _ptr(ic), _ptr(tr), _ptr(se), _ptr(self.obs_inter),
+                                               _ptr(self.obs_intra), _ptr(self.reward), _ptr(self.done),
+                                               self._stream()), "ranenv_step")
+        self._keep["last_inputs"] = (sc, ic, tr, se)
+        return self._obs(), self.reward, self.done
+
+    def step_dense(self, sched_decision, traffic_bits=None, se_tiles=None):
+        """One TTI with a caller-made dense sched_decision [B,U,R] (any agent's action_format)."""
+        sd = self._dev(sched_decision, torch.uint8, (self.B, self.U, self.R), "sched_decision")
+        tr = self._dev(traffic_bits, torch.float64, (self.B, self.U), "traffic_bits")
+        se = self._dev(se_tiles, torch.float32, (self.B, self.R, self.U), "se_tiles")
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_step_dense(self._h, _ptr(sd), _ptr(tr), _ptr(se), _ptr(self.obs_inter),
+                                                     _ptr(self.obs_intra), _ptr(self.reward), _ptr(self.done),
+                                                     self._stream()), "ranenv_step_dense")
+        self._keep["last_inputs"] = (sd, tr, se)
+        return self._obs(), self.reward, self.done
+
+    # ------------------------------------------------------------------------------------------
+    def views(self) -> Dict[str, torch.Tensor]:
+        """Zero-copy torch views of the handle's raw-observation and state arrays."""
+        if self._views is None:
+            v = _lib.Views()
+            self._check(self._lib.ranenv_get_views(self._h, C.byref(v)), "ranenv_get_views")
+            dims = {"B": self.B, "U": self.U, "S": self.S, "K": self.Us}
+            out = {}
+            for name, ts, shp in _lib.VIEW_FIELDS:
+                shape = tuple(dims[c] for c in shp)
+                arr = _DevArray(getattr(v, name), shape, ts, self)
+                out[name] = torch.as_tensor(arr, device=self.device)
+                assert out[name].dtype == _TORCH_DT[ts]
+            self._views = out
+        return self._views
+
+    def raw_observation(self) -> Dict[str, torch.Tensor]:
+        """The reference's raw-observation metric fields (agents/ib_sched.py:78-181), batched."""
+        v = self.views()
+        if self.tables is None or self.episodes is None:
+            raise RanEnvError("raw_observation needs load_scenarios + set_episodes")
+        scen = torch.as_tensor(self.episodes["scenario"].astype(np.int64), device=self.device)
+        max_pkts = torch.as_tensor(self.tables.ue_max_pkts, device=self.device)[scen].to(torch.float64)
+        q = v["queue_pkts"].to(torch.float64)
+        lat = torch.where(q > 0, v["queue_age_sum"].to(torch.float64) / q.clamp(min=1), torch.zeros_like(q))
+        return {
+            "pkt_incoming": v["pkt_incoming"].to(torch.float64),
+            "pkt_throughputs": v["pkt_throughputs"].to(torch.float64),
+            "pkt_effective_thr": v["pkt_effective_thr"].to(torch.float64),
+            "dropped_pkts": v["dropped_pkts"].to(torch.float64),
+            "buffer_occupancies": q / max_pkts,
+            "buffer_latencies": lat,
+        }
+
+    def launch_info(self):
+        g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.ranenv_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)), "ranenv_launch_info")
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    def algorithmic_bytes_per_env_step(self) -> int:
+        """4*U*R + 180*U + S*(85 + 8*Us) + 4."""
+        return 4 * self.U * self.R + 180 * self.U + self.S * (85 + 8 * self.Us) + 4

@@ -299,14 +299,16 @@ class ScenarioTables:
 
     def validate(self, max_age_cap: int, n_rbs: int, bandwidth_hz: float, max_se: float = 64.0) -> None:
         """Refuse tables the int32 device state cannot represent."""
-        if int(self.ue_max_age.max(initial=0)) > max_age_cap:
+        if self.n_scenarios == 0:
+            return
+        if int(self.ue_max_age.max()) > max_age_cap:
             raise ValueError(f"buffer_latency {int(self.ue_max_age.max())} exceeds max_age_cap {max_age_cap}")
-        if int(self.ue_pkt_size.min(initial=1)) <= 0 or int(self.ue_max_pkts.min(initial=1)) <= 0:
+        if int(self.ue_pkt_size.min()) <= 0 or int(self.ue_max_pkts.min()) <= 0:
             raise ValueError("pkt_size and max_buffer_pkts must be positive")
-        worst = bandwidth_hz * max_se / float(self.ue_pkt_size.min(initial=1))
+        worst = bandwidth_hz * max_se / float(self.ue_pkt_size.min())
         if worst >= 2 ** 31:
             raise ValueError("per-TTI packet capacity may overflow int32; raise message_size")
-        if int(self.slice_nues.max(initial=0)) > self.max_ues_slice:
+        if int(self.slice_nues.max()) > self.max_ues_slice:
             raise ValueError("slice_nues exceeds max_ues_slice")
 
 

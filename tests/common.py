@@ -26,3 +26,21 @@ TRACE_CASES = ["trace_ref_random", "trace_ref_marr", "trace_ref_mapf", "trace_sc
 # float tolerance between the oracle and the reference's own outputs: both are IEEE double in
 # numpy's operation order, so they agree to rounding of a handful of operations.
 RTOL, ATOL = 1e-12, 1e-12
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic batches shared by GPU tests, smoke() and bench.py's checker
+# ----------------------------------------------------------------------------------------------
+def poisson_traffic_rows(tables: ScenarioTables, scen: int, rng: np.random.Generator, steps: int) -> np.ndarray:
+    """[steps, U] offered bits in MultSliceTraffic.step's draw order
+    (traffics/mult_slice.py:24-32: slices in index order, UEs ascending, Poisson(Mbps)*1e6)."""
+    U, S = tables.n_ues, tables.n_slices
+    out = np.zeros((steps, U))
+    for t in range(steps):
+        for s in range(S):
+            if not tables.slice_has_req[scen, s]:
+                continue
+            n = int(tables.slice_nues[scen, s])
+            ues = tables.slice_ues[scen, s, :n]
+            out[t, ues] = rng.poisson(tables.slice_traffic[scen, s], n) * 1e6
+    return out
