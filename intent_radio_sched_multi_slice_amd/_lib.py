@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libranenv_hip.so")
+LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranenv_hip.so")
 
 ABI_VERSION = 1
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
@@ -79,6 +79,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime; it has to be in the process before this library's
+    # DT_NEEDED libamdhip64 is resolved, or two runtimes end up loaded and the second sees no GPU.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RanEnvError(
             f"{LIB_PATH} is missing: build it with `python -m intent_radio_sched_multi_slice_amd.csrc.build` "

@@ -85,6 +85,10 @@ class BatchedRanEnv:
         self.done = torch.zeros((B,), dtype=torch.uint8, device=dev)
         self.tables: Optional[ScenarioTables] = None
         self.episodes: Optional[np.ndarray] = None
+        # cached ctypes views of the output buffers (the per-step call is on the hot path)
+        self._obs_dict = {"obs_inter": self.obs_inter, "obs_intra": self.obs_intra}
+        self._p_out = (_ptr(self.obs_inter), _ptr(self.obs_intra), _ptr(self.reward), _ptr(self.done))
+        self._step_fn = self._lib.ranenv_step
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -171,7 +175,7 @@ class BatchedRanEnv:
 
     # ------------------------------------------------------------------------------------------
     def _obs(self):
-        return {"obs_inter": self.obs_inter, "obs_intra": self.obs_intra}
+        return self._obs_dict
 
     def reset(self, env_mask=None, se_tiles=None):
         """CommunicationEnv.reset for the masked envs (all when None); returns the formatted obs."""
@@ -186,6 +190,13 @@ class BatchedRanEnv:
 
     def step(self, inter_scores=None, intra_choice=None, traffic_bits=None, se_tiles=None):
         """One TTI for all envs.  Returns (obs, reward [B,S+1] float64, done [B] uint8)."""
+        if inter_scores is None and intra_choice is None and traffic_bits is None and se_tiles is None:
+            # device policy + pools: nothing to marshal, just enqueue the launch
+            st = self._step_fn(self._h, None, None, None, None, *self._p_out,
+                               C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            if st != 0:
+                self._check(st, "ranenv_step")
+            return self._obs(), self.reward, self.done
         sc = self._dev(inter_scores, torch.float64, (self.B, self.S), "inter_scores")
         ic = self._dev(intra_choice, torch.uint8, (self.B, self.S), "intra_choice")
         tr = self._dev(traffic_bits, torch.float64, (self.B, self.U), "traffic_bits")

@@ -1,0 +1,92 @@
+"""Synthetic workloads for the BASELINE.json configurations.
+
+Everything an episode replays is exogenous and action-independent, as the reference requires
+(results/gen_results.py:1587-1635): a scenario pool (association + slice intents), an SE pool
+(channel traces) and a traffic pool (Poisson draws), all resident in HBM before stepping.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import INTRA_PF, INTRA_RR, POLICY_MAPF, POLICY_MARR
+from .batched_env import BatchedRanEnv
+from .scenario import ScenarioTables, generate_scaled_scenarios
+
+
+@dataclass
+class Workload:
+    name: str
+    env: BatchedRanEnv
+    tables: ScenarioTables
+    se_pool: torch.Tensor        # [tiles, R, U] float32
+    traffic_pool: torch.Tensor   # [rows, U] int32
+    scenario: np.ndarray         # [B]
+    se_trace: np.ndarray
+    se_offset: np.ndarray
+    trace_len: int
+    policy: int
+    intra: int
+
+
+def mimic_quadriga_pool(n_traces: int, trace_len: int, n_ues: int, n_rbs: int, seed: int,
+                        device: torch.device, chunk: int = 2048) -> torch.Tensor:
+    """SE pool following the MimicQuadriga law (channels/mimic_quadriga.py:37-56): per-trace
+    per-UE mean |N(10, 7.5)|, per-TTI per-RB |N(mean, 1.5)|, stored float32 RB-major."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    pool = torch.empty((n_traces * trace_len, n_rbs, n_ues), dtype=torch.float32, device=device)
+    mu = (torch.randn((n_traces, 1, 1, n_ues), generator=g, device=device) * 7.5 + 10.0).abs()
+    per = max(1, chunk // trace_len)
+    for t0 in range(0, n_traces, per):
+        t1 = min(n_traces, t0 + per)
+        z = torch.randn((t1 - t0, trace_len, n_rbs, n_ues), generator=g, device=device)
+        pool[t0 * trace_len:t1 * trace_len] = (mu[t0:t1] + 1.5 * z).abs().reshape(-1, n_rbs, n_ues)
+    return pool
+
+
+def poisson_traffic_pool(tables: ScenarioTables, trace_len: int, seed: int) -> np.ndarray:
+    """[n_scenarios*trace_len, U] int32 offered bits: Poisson(slice Mbps) * 1e6 for the UEs of each
+    slice (traffics/mult_slice.py:26-32); one trace per scenario."""
+    rng = np.random.default_rng(seed)
+    ns, U = tables.n_scenarios, tables.n_ues
+    lam = np.zeros((ns, U))
+    for i in range(ns):
+        for s in range(tables.n_slices):
+            n = int(tables.slice_nues[i, s])
+            if tables.slice_has_req[i, s] and n:
+                lam[i, tables.slice_ues[i, s, :n]] = tables.slice_traffic[i, s]
+    draws = rng.poisson(np.broadcast_to(lam[:, None, :], (ns, trace_len, U)))
+    return (draws.astype(np.int64) * 1_000_000).astype(np.int32).reshape(ns * trace_len, U)
+
+
+def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POLICY_MAPF, intra: int = INTRA_PF,
+                             n_scenarios: int = 200, n_traces: int = 200, trace_len: int = 200, seed: int = 10,
+                             n_slices: int = 10, n_ues: int = 100, n_rbs: int = 135, rbs_per_rbg: int = 1,
+                             max_ues_slice: int = 10, max_steps: int = 1000, rank: int = 0,
+                             name: Optional[str] = None, flags: int = 0) -> Workload:
+    """BASELINE configs 2-4: S 10 / U 100 / R 135 allocation units, 6..10 active slices with
+    distinct templates, 4..10 UEs per slice, MimicQuadriga-law SE replayed from HBM."""
+    tables = generate_scaled_scenarios(n_scenarios, seed=seed, n_slices=n_slices, n_ues=n_ues,
+                                       max_ues_slice=max_ues_slice,
+                                       min_slices=min(6, n_slices), min_ues=min(4, max_ues_slice))
+    env = BatchedRanEnv(batch=batch, n_slices=n_slices, n_ues=n_ues, n_rbs=n_rbs, rbs_per_rbg=rbs_per_rbg,
+                        max_ues_slice=max_ues_slice, n_scenarios=n_scenarios, max_steps=max_steps,
+                        device=device, flags=flags)
+    env.load_scenarios(tables)
+    se_pool = mimic_quadriga_pool(n_traces, trace_len, n_ues, n_rbs, seed + 1000 * (rank + 1), env.device)
+    trf = torch.from_numpy(poisson_traffic_pool(tables, trace_len, seed + 7)).to(env.device)
+    env.bind_se_pool(se_pool)
+    env.bind_traffic_pool(trf)
+    rng = np.random.default_rng(seed + 31 * (rank + 1))
+    scenario = rng.integers(0, n_scenarios, batch)
+    se_trace = (np.arange(batch) + rank * batch) % n_traces       # env -> trace id = e mod T
+    se_offset = rng.integers(0, trace_len, batch)
+    env.set_episodes(scenario=scenario, se_base=se_trace * trace_len, se_len=trace_len, se_offset=se_offset,
+                     trf_base=scenario * trace_len, trf_len=trace_len, trf_offset=rng.integers(0, trace_len, batch))
+    env.set_policy(policy, intra)
+    return Workload(name or f"mult_slice S{n_slices}/U{n_ues}/R{n_rbs} B{batch}", env, tables, se_pool, trf,
+                    scenario, se_trace, se_offset, trace_len, policy, intra)
