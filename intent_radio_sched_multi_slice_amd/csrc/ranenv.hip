@@ -68,6 +68,7 @@ struct State {
     int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
     int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
+    double *drift;              // [B][U][3] per-UE intent drift, core -> obs
 };
 
 struct KP {
@@ -86,94 +87,36 @@ struct KP {
     float *obs_inter; float *obs_intra; double *reward; uint8_t *done;
 };
 
-// LDS carve-up, shared by host (size) and device (offsets). All sizes in bytes, doubles first.
-// Rows that the unrolled 16-wide readers may over-read are padded (PAD entries).
-struct LdsLayout {
-    int d_occ, d_sem, d_hmean, d_semn, d_occn, d_part, d_drift, c_a, c_b, c_c, c_d, d_scores, d_tmp,
-        d_slvals, d_slflags, d_par, d_slf, i_slice, i_pos, i_pkt, i_maxp, i_maxage, i_start, i_count, i_sl,
-        i_slues, i_par, i_rbs, i_off, i_cnt, i_sel, i_nz, i_choice, i_misc, f_obs_inter, f_obs_intra, total;
-};
-constexpr int PAD = 16;
-
-__host__ __device__ inline LdsLayout make_layout(int S, int U, int Us)
-{
-    // Regions whose lifetimes do not overlap share storage:
-    //   d_sem (previous mean SE, read by P3)     <-> d_semn (new mean SE, written by P4)
-    //   d_hmean (window mean, read by P1/P3)     <-> d_part (allocated-RB SE sum, written by P4)
-    //   c_a|c_b|c_c (P1/P3 per-slice rows)       <-> d_drift (zeroed after P4, written by P5)
-    //   i_pkt|i_maxp|i_maxage|i_start (<= P5)    <-> f_obs_inter|f_obs_intra (P6)
-    LdsLayout l;
-    int o = 0;
-    auto take = [&](int bytes) { int r = o; o += (bytes + 7) & ~7; return r; };
-    l.d_occ = take(8 * U);  l.d_sem = take(8 * U);  l.d_hmean = take(8 * U); l.d_occn = take(8 * U);
-    l.d_semn = l.d_sem; l.d_part = l.d_hmean;
-    l.c_a = take(8 * (S * Us + PAD)); l.c_b = take(8 * (S * Us + PAD)); l.c_c = take(8 * (S * Us + PAD));
-    l.d_drift = l.c_a;                               // 8*(3*S*Us + 3*PAD) bytes, exactly c_a..c_c
-    l.c_d = take(8 * (S * Us + PAD));
-    l.d_scores = take(8 * (S + PAD)); l.d_tmp = take(8 * (5 * S + PAD));
-    l.d_slvals = take(8 * 3 * S); l.d_slflags = take(8 * 3 * S);
-    l.d_par = take(8 * 3 * S); l.d_slf = take(8 * 2 * S);
-    l.i_slice = take(4 * U); l.i_pos = take(4 * U); l.i_count = take(4 * U);
-    const int ue_tail = 4 * 4 * U, obs = 4 * 10 * S + 4 * S * (2 * Us + 9);
-    const int shared = take(ue_tail > obs ? ue_tail : obs);
-    l.i_pkt = shared; l.i_maxp = shared + 4 * U; l.i_maxage = shared + 8 * U; l.i_start = shared + 12 * U;
-    l.f_obs_inter = shared; l.f_obs_intra = shared + 4 * 10 * S;
-    l.i_sl = take(4 * 8 * S); l.i_slues = take(4 * (S * Us + PAD)); l.i_par = take(4 * 6 * S);
-    l.i_rbs = take(4 * (S + PAD)); l.i_off = take(4 * (S + PAD)); l.i_cnt = take(4 * (S * Us + PAD));
-    l.i_sel = take(4 * (S * Us + PAD)); l.i_nz = take(4 * S); l.i_choice = take(4 * S);
-    l.i_misc = take(4 * 8);
-    l.total = o;
-    return l;
-}
-
 // ---------------------------------------------------------------------------------------------
 // numpy arithmetic on the device
 // ---------------------------------------------------------------------------------------------
 DEVFN bool d_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * fabs(b)); }
 
-// Visit i = 0..n-1 in chunks of 16 with the body fully unrolled: the LDS reads of a chunk are
-// independent and issue back to back (one latency per chunk instead of one per element).  The body
-// gets (i, valid); it may read element i unconditionally (arrays are padded by PAD) and must ignore
-// the value when !valid.
-template <typename F>
-DEVFN void for16(int n, F body)
+// numpy pairwise_sum of n <= 16 doubles held in registers (x[j] for j >= n is ignored).
+// Missing elements count as +0.0, which turns numpy's three shapes for n <= 16 (n < 8 plain loop;
+// 8 <= n < 16 tree of the first 8 + sequential tail; n == 16 tree of 8 pair sums) into plain
+// expressions, since x + 0.0 == x exactly.
+DEVFN double np_sum16(const double (&xin)[16], int n)
 {
-    for (int i0 = 0; i0 < n; i0 += 16) {
+    double x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) body(i0 + j, i0 + j < n);
-    }
+    for (int j = 0; j < 16; j++) x[j] = j < n ? xin[j] : 0.0;
+    const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
+    double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+#pragma unroll
+    for (int j = 8; j < 15; j++) t8 += x[j];
+    const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
+                       (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
+    return n < 8 ? seq : (n < 16 ? t8 : t16);
 }
 
-// numpy pairwise_sum (one leaf, n <= 128) over strided doubles in LDS.  n <= 16 is the hot case
-// (slices, UEs of a slice): all 16 reads are issued up front, missing elements read as +0.0, which
-// makes the three numpy shapes (n < 8 plain loop; 8 <= n < 16 tree of 8 + sequential tail; n == 16
-// tree of 8 pair sums) plain expressions (x + 0.0 == x exactly).
-DEVFN double np_sum_lds(const double *a, int n, int stride)
+// the same over a row of 16 doubles in LDS (all 16 reads issue back to back)
+DEVFN double np_sum16_lds(const double *row, int n)
 {
-    if (n <= 16) {
-        double x[16];
+    double x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const double v = a[j * stride]; x[j] = j < n ? v : 0.0; }
-        const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
-        double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-#pragma unroll
-        for (int j = 8; j < 15; j++) t8 += x[j];
-        const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
-                           (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
-        return n < 8 ? seq : (n < 16 ? t8 : t16);
-    }
-    double r0 = a[0], r1 = a[stride], r2 = a[2 * stride], r3 = a[3 * stride];
-    double r4 = a[4 * stride], r5 = a[5 * stride], r6 = a[6 * stride], r7 = a[7 * stride];
-    int i;
-    const int m = n - (n % 8);
-    for (i = 8; i < m; i += 8) {
-        const double *q = a + i * stride;
-        r0 += q[0]; r1 += q[stride]; r2 += q[2 * stride]; r3 += q[3 * stride];
-        r4 += q[4 * stride]; r5 += q[5 * stride]; r6 += q[6 * stride]; r7 += q[7 * stride];
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += a[i * stride];
-    return res;
+    for (int j = 0; j < 16; j++) x[j] = row[j];
+    return np_sum16(x, n);
 }
 
 DEVFN bool d_apply_op(int op, double a, double b)
@@ -186,6 +129,9 @@ DEVFN bool d_apply_op(int op, double a, double b)
     default: return a < b;
     }
 }
+
+constexpr int WAVE = 64;
+constexpr int GRP = 16;   // lanes per (env) group in alloc1/obs and per (env, slice) group in alloc2
 
 // ---------------------------------------------------------------------------------------------
 // SE row reduction: software-pipelined stream + numpy's pairwise order
@@ -322,647 +268,548 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     full = lf + rf; part = lg + rg;
 }
 
-// ---------------------------------------------------------------------------------------------
-// the step kernel
-// ---------------------------------------------------------------------------------------------
-#define RANENV_STAMP(k)                                                                        \
-    do {                                                                                       \
-        if (RANENV_DIAG == 9 && MODE == MODE_STEP) {                                           \
-            unsigned long long ts_;                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                 \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_)::"memory");       \
-            __builtin_amdgcn_sched_barrier(0);                                                 \
-            if (threadIdx.x == 0) stamps[(k)] = ts_;                                           \
-        }                                                                                      \
-    } while (0)
+#define RANENV_STAMP(k) do { } while (0)
 
-// One wavefront (64 lanes) steps one environment: every exchange between lanes goes through LDS
-// inside the wave, so the phase boundaries below cost an LDS wait, not a workgroup barrier, and a CU
-// keeps twice as many environments in flight as with a two-wave workgroup.  UE u is handled by lane
-// u mod 64 in pass u / 64 of every per-UE phase; slice s by lane s of the per-slice phases.
-constexpr int WAVE = 64;
+// =============================================================================================
+// Kernel 1/3  alloc: one workgroup = one env, thread = (slice s = tid / 16, UE slot = tid % 16).
+//   Policy  MARR agents/marr.py:40-47, MAPF agents/mapf.py:41-111
+//   Inter   IBSched.action_format agents/ib_sched.py:240-269, scores_to_rbs / round_int_equal_sum
+//           agents/common.py:442-505          (threads 0..15, one per slice)
+//   Intra   round_robin agents/common.py:508-555, proportional_fairness :558-636,
+//           max_throughput :639-701, distribute_rbs_ues :464-478   (16 lanes per slice)
+// =============================================================================================
+constexpr int ALLOC_NT = GRP * GRP;   // 256
 
-// PASSES > 0: number of 64-UE passes known at compile time (loops fully unrolled, so the passes'
-// dependency chains interleave); PASSES == 0: generic run-time loop.
-#define FOR_PASS _Pragma("unroll") for (int pass = 0; pass < (PASSES > 0 ? PASSES : passes); pass++)
-
-template <int MODE, int PASSES>
-__global__ void __launch_bounds__(WAVE) ranenv_kernel(const KP p)
+__global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 {
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (p.env_mask != nullptr && p.env_mask[b] == 0) return;  // uniform per workgroup
-    unsigned long long stamps[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    RANENV_STAMP(0);
+    __shared__ double xs[4][GRP];            // cross-slice rows
+    __shared__ double rows[GRP][2][GRP];     // per-slice rows
+    __shared__ int sh_rbs[GRP], sh_off[GRP];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int s = tid / GRP, pos = tid % GRP;          // intra role: (slice, UE slot)
+    const int S = p.S, U = p.U, Us = p.Us;
+    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
+    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
+    double *ra = rows[s][0], *rb = rows[s][1];
 
-    const int S = p.S, U = p.U, R = p.R, Us = p.Us, D = p.D;
-    const int W = 2 * Us + 9;
-    const int passes = PASSES > 0 ? PASSES : (U + WAVE - 1) / WAVE;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const LdsLayout lo = make_layout(S, U, Us);
-    double *d_occ = (double *)(smem + lo.d_occ), *d_sem = (double *)(smem + lo.d_sem);
-    double *d_hmean = (double *)(smem + lo.d_hmean), *d_semn = (double *)(smem + lo.d_semn);
-    double *d_occn = (double *)(smem + lo.d_occn), *d_part = (double *)(smem + lo.d_part);
-    double *d_drift = (double *)(smem + lo.d_drift);
-    double *c_a = (double *)(smem + lo.c_a), *c_b = (double *)(smem + lo.c_b);
-    double *c_c = (double *)(smem + lo.c_c), *c_d = (double *)(smem + lo.c_d);
-    double *d_scores = (double *)(smem + lo.d_scores), *d_tmp = (double *)(smem + lo.d_tmp);
-    double *d_slvals = (double *)(smem + lo.d_slvals), *d_slflags = (double *)(smem + lo.d_slflags);
-    double *d_par = (double *)(smem + lo.d_par), *d_slf = (double *)(smem + lo.d_slf);
-    int *i_slice = (int *)(smem + lo.i_slice), *i_pos = (int *)(smem + lo.i_pos), *i_pkt = (int *)(smem + lo.i_pkt);
-    int *i_maxp = (int *)(smem + lo.i_maxp), *i_maxage = (int *)(smem + lo.i_maxage);
-    int *i_start = (int *)(smem + lo.i_start), *i_count = (int *)(smem + lo.i_count);
-    int *i_sl = (int *)(smem + lo.i_sl), *i_slues = (int *)(smem + lo.i_slues), *i_par = (int *)(smem + lo.i_par);
-    int *i_rbs = (int *)(smem + lo.i_rbs), *i_off = (int *)(smem + lo.i_off), *i_cnt = (int *)(smem + lo.i_cnt);
-    int *i_sel = (int *)(smem + lo.i_sel), *i_nz = (int *)(smem + lo.i_nz), *i_choice = (int *)(smem + lo.i_choice);
-    int *i_misc = (int *)(smem + lo.i_misc);
-    float *f_obs_inter = (float *)(smem + lo.f_obs_inter), *f_obs_intra = (float *)(smem + lo.f_obs_intra);
+    // ---- this thread's UE (slot pos of slice s) ------------------------------------------------
+    int n = 0;
+    if (s < S) n = p.tab.slice_i32[((size_t)sc * S + s) * 8 + 2];
+    const bool have = s < S && pos < n;
+    int ue = 0, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
+    if (have) {
+        ue = p.tab.slice_ues[((size_t)sc * S + s) * Us + pos];
+        q = p.st.queue_pkts[(size_t)e * U + ue]; wsent = p.st.win_sent[(size_t)e * U + ue];
+        sem = p.st.se_mean[(size_t)e * U + ue];
+        mp = p.tab.ue_max_pkts[(size_t)sc * U + ue]; pk = p.tab.ue_pkt_size[(size_t)sc * U + ue];
+    }
+    const double occ = (double)q / (double)mp;
+    const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
+    const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
+    if (mapf) { ra[pos] = have ? occ : 0.0; rb[pos] = have ? hm : 0.0; }
 
-    // ---- P0: per-env scalars, per-UE state, scenario tables -------------------------------------
-    // Everything read here is the same for the whole wave: pin it to scalar registers so the
-    // SE loads below use the saddr + 32-bit lane-offset form instead of per-lane 64-bit addresses.
+    // ---- inter role: thread t < 16 is slice t ---------------------------------------------------
+    const int s1 = tid;
+    const bool ok1 = tid < GRP && s1 < S;
+    int active = 0, nues1 = 0, bsize = 1, msg = 1, sorted = 0;
+    if (ok1) {
+        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s1) * 8;
+        active = si[0]; nues1 = si[2]; bsize = si[3]; msg = si[5]; sorted = si[7];
+    }
+    __syncthreads();
+    double score = -1.0;
+    if (mapf) {
+        double occ_mb = 0.0, thr_mb = 0.0;
+        if (ok1 && active) {
+            const double pkt = (double)msg, bmax = (double)bsize;
+            occ_mb = ((np_sum16_lds(rows[s1][0], nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
+            thr_mb = ((np_sum16_lds(rows[s1][1], nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+        }
+        if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
+        __syncthreads();
+        double w = 0.0;
+        if (tid < GRP) {
+            double mx = xs[0][0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) { const double v = xs[0][j]; mx = (j < S && v > mx) ? v : mx; }
+            w = d_isclose(thr_mb, 0.0) ? 2.0 * mx : occ_mb / thr_mb;                            // :91-100
+            if (!active) w = 0.0;
+            xs[2][s1] = ok1 ? w : 0.0;
+        }
+        __syncthreads();
+        if (tid < GRP) {
+            const double ws = np_sum16_lds(xs[2], S);
+            score = (ws > 0.0 ? w / ws : 2.0) - 1.0;                                            // :105-109
+        }
+        __syncthreads();
+    } else if (ok1) {
+        score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);
+    }
+    if (ok1) p.st.policy_scores[(size_t)e * S + s1] = score;
+    if (tid < GRP) xs[3][s1] = score;
+    __syncthreads();
+    const int T = p.R / p.G;
+    double my_a = -1.0;
+    if (tid < GRP) {
+        my_a = (ok1 && active) ? xs[3][sorted] : -1.0;                                           // ib_sched.py:247-255
+        xs[0][s1] = ok1 ? my_a + 1.0 : 0.0;
+        xs[1][s1] = ok1 ? (double)active : 0.0;
+    }
+    __syncthreads();
+    double my_v = 0.0; bool nzf = false; int m_nz = 0, slot = 0;
+    if (tid < GRP) {
+        const double ssum = np_sum16_lds(xs[0], S), asum = np_sum16_lds(xs[1], S);
+        if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
+        nzf = my_v != 0.0;
+        // compaction of the non-zero values in slice order (common.py:484-485)
+        const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull);
+        m_nz = __popc(gm); slot = __popc(gm & ((1u << s1) - 1u));
+        xs[2][s1] = 0.0;
+    }
+    __syncthreads();
+    if (tid < GRP) { if (nzf) xs[2][slot] = my_v; xs[3][s1] = my_v; }
+    __syncthreads();
+    if (tid < GRP) {
+        const double tot = np_sum16_lds(xs[2], m_nz);
+        const int my_prop = nzf ? (int)((double)T * my_v / tot) : 0;                  // :488-490 (value >= 0)
+        int acc = my_prop;
+#pragma unroll
+        for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+        const int adj = T - acc;                                                     // :493-499
+        int extra = 0;
+        if (nzf && adj > 0) {
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
+            extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
+        }
+        const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (s1 >= d) ? v : 0; }
+        sh_rbs[s1] = mine; sh_off[s1] = incl - mine;
+    }
+    __syncthreads();
+
+    // ---- intra-slice: 16 lanes per slice ---------------------------------------------------------
+    const int n_rbs = s < S ? sh_rbs[s] : 0, off = s < S ? sh_off[s] : 0;
+    int choice = p.fixed_intra;
+    if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && s < S) ? (int)p.intra[(size_t)e * S + s] : RANENV_INTRA_RR;
+    const bool has_pkts = have && !d_isclose(occ, 0.0);
+    double avail = 0.0;                          // PF / MT path, evaluated by every slice
+    if (have) {
+        const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // :573-578
+        const double cap = sem * slice_bw / (double)n;
+        const double backlog = occ * (double)mp * (double)pk;
+        avail = cap < backlog ? cap : backlog;
+    }
+    ra[pos] = avail;
+    __syncthreads();
+    double num = avail;                                                            // MT: weights = avail
+    if (choice == RANENV_INTRA_PF) {                                               // :584-602
+        double max_avail = ra[0];
+#pragma unroll
+        for (int k = 1; k < 16; k++) { const double av = ra[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+        double snt = hm * (double)pk;
+        if (d_isclose(avail, 0.0)) snt = 1.0;
+        num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
+    }
+    rb[pos] = have ? num : 0.0;
+    __syncthreads();
+    const double wsum = np_sum16_lds(rb, n);
+    const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
+    const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
+    const bool nzv = my_val != 0.0;
+    const int gsh = (tid & 63) & ~(GRP - 1);
+    const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
+    const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
+    __syncthreads();
+    ra[pos] = 0.0;
+    __syncthreads();
+    if (nzv) ra[slot_v] = my_val;                                                  // compaction (:484-485)
+    rb[pos] = my_val;
+    __syncthreads();
+    int count = 0;
+    if (use_round) {
+        const double tot = np_sum16_lds(ra, m_v);
+        const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
+        int acc = prop;
+#pragma unroll
+        for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+        const int adj = n_rbs - acc;
+        count = prop;
+        if (nzv && adj > 0) {
+            int rank = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { const double xk = rb[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+            count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
+        }
+    } else {
+        // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
+        const bool account = choice == RANENV_INTRA_RR;
+        const unsigned gmr = (unsigned)((__ballot(has_pkts && account) >> gsh) & 0xffffull);
+        int k_sel = __popc(gmr), idx = __popc(gmr & ((1u << pos) - 1u));
+        const bool all = (k_sel == 0);
+        if (all) { k_sel = n; idx = pos; }
+        if (have && (all || has_pkts) && k_sel > 0) {
+            const unsigned each = (unsigned)n_rbs / (unsigned)k_sel, rem = (unsigned)n_rbs - each * (unsigned)k_sel;
+            count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
+        }
+    }
+    int incl = count;                                                              // :464-478 contiguous ranges
+#pragma unroll
+    for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (pos >= d) ? v : 0; }
+    if (have) {
+        p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
+        p.st.rb_count[(size_t)e * U + ue] = count;
+    }
+}
+
+// =============================================================================================
+// Kernel 2/3  core: lane = UE.  SE row stream -> capacity -> UEs.step -> intent drift.
+//   No LDS, no barriers: everything a UE needs is its own row, its own state and its slice's
+//   table row.  UEs.step / Buffer: oracle/ranenv_oracle.c (sixg_radio_mgmt is un-vendored);
+//   intent_drift_calc agents/common.py:68-340.
+// =============================================================================================
+template <int MODE, int NT>
+__global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
+{
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
+    const int S = p.S, U = p.U, R = p.R, D = p.D;
+
+    // Everything read here is the same for the whole workgroup: pin it to scalar registers so the
+    // SE loads use the saddr + 32-bit lane-offset form instead of per-lane 64-bit addresses.
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto uni64 = [](long long v) {
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
     };
-    ranenv_episode ep = p.episodes[b];
-    ep.scenario = uni(ep.scenario); ep.se_len = uni(ep.se_len); ep.se_offset = uni(ep.se_offset);
-    ep.trf_len = uni(ep.trf_len); ep.trf_offset = uni(ep.trf_offset);
+    ranenv_episode ep = p.episodes[e];
+    ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
     ep.se_base = uni64(ep.se_base); ep.trf_base = uni64(ep.trf_base);
     const int sc = ep.scenario;
-    const int step = (MODE == MODE_RESET) ? 0 : uni(p.st.step_no[b]);
-    int hlen = uni(p.st.hist_len[b]);
-    const int npush = uni(p.st.n_push[b]);                    // kept in [0, D)
-    // position inside the env's SE / traffic trace: offset at reset, +1 (wrapping) per TTI
-    const int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[b]);
-    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[b]);
+    const int t = (MODE == MODE_RESET) ? 0 : uni(p.st.step_no[e]);
+    int hlen = uni(p.st.hist_len[e]);
+    const int npush = uni(p.st.n_push[e]);                    // kept in [0, D)
+    const int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[e]);
+    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[e]);
     const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
     if (clear_hist) hlen = 0;
-    const int t = step;
     const int hlen_new = hlen < D ? hlen + 1 : D;
 
     const float *tile;
-    if (p.se_tiles != nullptr) tile = p.se_tiles + (size_t)b * U * R;
+    if (p.se_tiles != nullptr) tile = p.se_tiles + (size_t)e * U * R;
     else tile = p.se_pool + (size_t)(ep.se_base + (long long)se_pos) * (size_t)p.se_stride;
 
-    // SE stream of pass 0: its first loads are in flight while the allocation phases run
-    SeStream se_a, se_b;
-    se_a.init(tile, U, lane < U ? lane : U - 1, R);
+    const bool act = tid < U;
+    const int u = act ? tid : U - 1;          // idle lanes shadow the last UE (loads stay in bounds)
+    SeStream se;
+    se.init(tile, U, u, R);                   // SE loads are in flight from here on
 
-    FOR_PASS {
-        const int u = pass * WAVE + lane;
-        if (u < U) {
-            const size_t su = (size_t)b * U + u, tu = (size_t)sc * U + u;
-            const int slc = p.tab.ue_slice[tu], pos = p.tab.ue_pos[tu];
-            const int pkt = p.tab.ue_pkt_size[tu], maxp = p.tab.ue_max_pkts[tu], maxage = p.tab.ue_max_age[tu];
-            int total = 0; long long wsent = 0; double sem_prev = 0.0;
-            if (MODE != MODE_RESET) { total = p.st.queue_pkts[su]; sem_prev = p.st.se_mean[su]; }
-            if (!clear_hist) wsent = p.st.win_sent[su];
-            const double occ = (double)total / (double)maxp;
-            const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
-            i_slice[u] = slc; i_pos[u] = pos; i_pkt[u] = pkt; i_maxp[u] = maxp; i_maxage[u] = maxage;
-            d_occ[u] = occ; d_sem[u] = sem_prev; d_hmean[u] = hm;
-            i_start[u] = 0; i_count[u] = 0;
-            if (slc >= 0) { c_a[slc * Us + pos] = occ; c_b[slc * Us + pos] = hm; }   // per-slice rows for MAPF
-        }
+    // ---- everything else this UE needs, issued before the row loop so it lands underneath it ----
+    const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
+    const int slc = p.tab.ue_slice[tu], ue_pos = p.tab.ue_pos[tu];
+    const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
+    int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
+    long long sum_age = 0, win_sent = 0, win_drop = 0;
+    if (MODE != MODE_RESET) {
+        total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
+        front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
     }
-    if (lane < S) {
-        const int s = lane;
-        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s) * 8;
-#pragma unroll
-        for (int k = 0; k < 8; k++) i_sl[s * 8 + k] = si[k];
-        d_slf[s * 2 + 0] = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 0];
-        d_slf[s * 2 + 1] = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 1];
+    if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
+    if (MODE == MODE_STEP && slc >= 0) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
+    int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
+    int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
+    int old_s = 0, old_d = 0;
+    if (hlen == D) { old_s = *rs; old_d = *rd; }
+    double traffic = 0.0;
+    if (MODE != MODE_RESET)
+        traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
+    // slice row for the drift (agents/common.py:9-65 needs message_size, buffer_size, buffer_latency)
+    int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
+    int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
+    double pv[3] = {0.0, 0.0, 0.0};
+    if (slc >= 0) {
+        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
+        has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            i_par[s * 6 + 2 * k + 0] = p.tab.param_i32[(((size_t)sc * S + s) * 3 + k) * 2 + 0];
-            i_par[s * 6 + 2 * k + 1] = p.tab.param_i32[(((size_t)sc * S + s) * 3 + k) * 2 + 1];
-            d_par[s * 3 + k] = p.tab.param_f64[((size_t)sc * S + s) * 3 + k];
+            pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
+            po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
+            pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
         }
-        int choice = p.fixed_intra;
-        if (choice == RANENV_INTRA_PER_SLICE) choice = (MODE == MODE_STEP && p.intra) ? (int)p.intra[(size_t)b * S + s] : RANENV_INTRA_RR;
-        i_choice[s] = choice;
     }
-    for (int i = lane; i < S * Us; i += WAVE) i_slues[i] = p.tab.slice_ues[(size_t)sc * S * Us + i];
-    __syncthreads();
-    RANENV_STAMP(1);
+    const double occ_prev = (double)total / (double)max_pkts;
 
-    // slice table accessors
-    auto sl_active = [&](int s) { return i_sl[s * 8 + 0]; };
-    auto sl_hasreq = [&](int s) { return i_sl[s * 8 + 1]; };
-    auto sl_nues = [&](int s) { return i_sl[s * 8 + 2]; };
-    auto sl_bsize = [&](int s) { return i_sl[s * 8 + 3]; };
-    auto sl_blat = [&](int s) { return i_sl[s * 8 + 4]; };
-    auto sl_msg = [&](int s) { return i_sl[s * 8 + 5]; };
-    auto sl_npar = [&](int s) { return i_sl[s * 8 + 6]; };
-    auto sl_sorted = [&](int pos) { return i_sl[pos * 8 + 7]; };
-
-    if (MODE == MODE_STEP && RANENV_DIAG != 1) {
-        // ---- P1: inter-slice scores: external, MARR (marr.py:40-47) or MAPF (mapf.py:41-111) ----
-        const bool ext = p.scores != nullptr;
-        if (!ext && p.policy == RANENV_POLICY_MAPF) {
-            if (lane < S) {
-                const int s = lane;
-                double occ_mb = 0.0, thr_mb = 0.0;
-                if (sl_active(s)) {
-                    const int n = sl_nues(s);
-                    const double pkt = (double)sl_msg(s), bmax = (double)sl_bsize(s);
-                    occ_mb = ((np_sum_lds(c_a + s * Us, n, 1) / (double)n * bmax) * pkt) / 1e6;
-                    thr_mb = ((np_sum_lds(c_b + s * Us, n, 1) / (double)n) * pkt) / 1e6;
-                }
-                d_tmp[s] = occ_mb; d_tmp[S + s] = thr_mb;
-            }
-            __syncthreads();
-            if (lane < S) {
-                const int s = lane;
-                double mx = d_tmp[0];
-                for16(S, [&](int j, bool ok) { const double v = d_tmp[j]; mx = (ok && v > mx) ? v : mx; });
-                double w = d_isclose(d_tmp[S + s], 0.0) ? 2.0 * mx : d_tmp[s] / d_tmp[S + s];
-                if (!sl_active(s)) w = 0.0;
-                d_tmp[2 * S + s] = w;
-            }
-            __syncthreads();
-            if (lane < S) {
-                const double ws = np_sum_lds(d_tmp + 2 * S, S, 1);
-                d_scores[lane] = (ws > 0.0 ? d_tmp[2 * S + lane] / ws : 2.0) - 1.0;
-            }
-        } else if (lane < S) {
-            d_scores[lane] = ext ? p.scores[(size_t)b * S + lane] : (sl_nues(lane) > 0 ? 1.0 : -1.0);
+    // ---- this UE's SE row: mean over all RBs and sum over its allocated RBs ----------------------
+    double se_full = 0.0, se_part = 0.0;
+    if (MODE == MODE_STEP) {
+        const unsigned ust = (unsigned)rb_start, ucn = (unsigned)rb_count;
+        row_sums(se, R, [=](int r) { return ((unsigned)r - ust) < ucn; }, se_full, se_part);
+    } else if (MODE == MODE_DENSE) {
+        const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
+        row_sums(se, R, [=](int r) { return mrow[r] != 0; }, se_full, se_part);
+        bool seen = false;
+        for (int r = 0; r < R; r++) {
+            if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
         }
-        __syncthreads();
-        RANENV_STAMP(2);
-
-        // ---- P2: inter-slice RBG split, one lane per slice (ib_sched.py:240-269, ------------------
-        //      common.py:442-461 scores_to_rbs, :481-505 round_int_equal_sum)
-        double *t_ap1 = d_tmp, *t_assoc = d_tmp + S, *t_v = d_tmp + 2 * S, *t_nz = d_tmp + 3 * S;
-        const int T = R / p.G;                                              // floor(R / G), uniform
-        double my_a = -1.0, my_v = 0.0;
-        if (lane < S) {
-            const int s = lane;
-            p.st.policy_scores[(size_t)b * S + s] = d_scores[s];
-            my_a = sl_active(s) ? d_scores[sl_sorted(s)] : -1.0;             // ib_sched.py:247-255
-            t_ap1[s] = my_a + 1.0;
-            t_assoc[s] = (double)sl_active(s);
-        }
-        __syncthreads();
-        int any_active = 0;
-        for16(S, [&](int j, bool ok) { const double v = t_assoc[j]; any_active += (ok && v != 0.0) ? 1 : 0; });
-        if (lane < S && any_active) {
-            const double ssum = np_sum_lds(t_ap1, S, 1);
-            if (ssum != 0.0) my_v = (double)T * (my_a + 1.0) / ssum;
-            else my_v = ((double)T / np_sum_lds(t_assoc, S, 1)) * t_assoc[lane];
-            t_v[lane] = my_v;
-        }
-        __syncthreads();
-        // compaction of the non-zero values (:484-485): entry of slice s goes to its rank among them
-        int m_nz = 0, my_slot = 0;
-        for16(S, [&](int j, bool ok) {
-            const double v = t_v[j];
-            const int nzf = (ok && any_active && v != 0.0) ? 1 : 0;
-            m_nz += nzf; my_slot += (j < lane) ? nzf : 0;
-        });
-        if (lane < S && any_active && my_v != 0.0) t_nz[my_slot] = my_v;
-        __syncthreads();
-        int my_prop = 0;
-        if (lane < S && any_active) {
-            const double tot = np_sum_lds(t_nz, m_nz, 1);
-            my_prop = my_v != 0.0 ? (int)((double)T * my_v / tot) : 0;      // :488-490 floor of a value >= 0
-            i_rbs[lane] = my_prop;
-        }
-        __syncthreads();
-        int mine = 0;
-        if (lane < S && any_active) {
-            int acc = 0, rank = 0;
-            for16(S, [&](int j, bool ok) {
-                const int pr = i_rbs[j]; const double xj = t_v[j];
-                acc += ok ? pr : 0;
-                rank += (ok && xj != 0.0 && (xj > my_v || (xj == my_v && j > lane))) ? 1 : 0;
-            });
-            const int adj = T - acc;                                         // :493-499
-            int extra = 0;
-            if (my_v != 0.0 && adj > 0 && m_nz > 0)   // hand-out i goes to sorted[i % m]; adj < m in exact arithmetic
-                extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
-            mine = (my_prop + extra) * p.G;                                  // ib_sched.py:268
-        }
-        __syncthreads();
-        if (lane < S) i_rbs[lane] = mine;
-        __syncthreads();
-        if (lane < S) {
-            int off = 0;
-            for16(S, [&](int j, bool ok) { const int v = i_rbs[j]; off += (ok && j < lane) ? v : 0; });
-            i_off[lane] = off;
-        }
-        __syncthreads();
-        RANENV_STAMP(3);
-
-        // ---- P3: intra-slice scheduling, one lane per UE (ib_sched.py:272-344) -------------------
-        //      RR common.py:508-555, PF :558-636, MT :639-701, distribute_rbs_ues :464-478
-        // stage A: RR selection flag and throughput_available
-        FOR_PASS {
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active) {
-                const int row = s * Us, pos = i_pos[u], n = sl_nues(s), n_rbs = i_rbs[s];
-                const double occ = d_occ[u];
-                i_sel[row + pos] = d_isclose(occ, 0.0) ? 0 : 1;              // RR: UEs with packets (:519-524)
-                if (i_choice[s] != RANENV_INTRA_RR) {
-                    const double slice_bw = (double)n_rbs * p.bw_hz / (double)R;   // :573-578
-                    const double cap = d_sem[u] * slice_bw / (double)n;
-                    const double backlog = occ * (double)i_maxp[u] * (double)i_pkt[u];
-                    c_a[row + pos] = cap < backlog ? cap : backlog;
-                }
-            }
-        }
-        __syncthreads();
-        // stage B: PF weights / MT weights
-        FOR_PASS {
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active && i_choice[s] != RANENV_INTRA_RR) {
-                const int row = s * Us, pos = i_pos[u], n = sl_nues(s);
-                const double my_avail = c_a[row + pos];
-                double my_num = my_avail;                                      // MT: weights = avail
-                if (i_choice[s] == RANENV_INTRA_PF) {                          // :584-602
-                    double max_avail = c_a[row];
-                    for16(n, [&](int k, bool ok) { const double av = c_a[row + k]; max_avail = (ok && av > max_avail) ? av : max_avail; });
-                    double snt = d_hmean[u] * (double)i_pkt[u];
-                    if (d_isclose(my_avail, 0.0)) snt = 1.0;
-                    my_num = d_isclose(snt, 0.0) ? 2.0 * max_avail : my_avail / snt;
-                }
-                c_b[row + pos] = my_num;
-            }
-        }
-        __syncthreads();
-        // stage C: proportional values, or fall back to round robin when the weights sum to 0
-        FOR_PASS {
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active && i_choice[s] != RANENV_INTRA_RR) {
-                const int row = s * Us, pos = i_pos[u], n = sl_nues(s), n_rbs = i_rbs[s];
-                const double wsum = np_sum_lds(c_b + row, n, 1);               // :603-608 (same for the whole slice)
-                c_c[row + pos] = wsum != 0.0 ? (double)n_rbs * c_b[row + pos] / wsum : 0.0;
-                if (pos == 0) i_nz[s] = wsum != 0.0 ? 1 : 0;                   // slice takes the round_int path
-            }
-        }
-        __syncthreads();
-        // stage D: compaction of each slice's non-zero values (:484-485), then floor shares
-        FOR_PASS {
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active && i_choice[s] != RANENV_INTRA_RR && i_nz[s] != 0) {
-                const int row = s * Us, pos = i_pos[u], n = sl_nues(s);
-                const double my_val = c_c[row + pos];
-                int slot = 0;
-                for16(n, [&](int k, bool ok) { const double v = c_c[row + k]; slot += (ok && k < pos && v != 0.0) ? 1 : 0; });
-                if (my_val != 0.0) c_d[row + slot] = my_val;
-            }
-        }
-        __syncthreads();
-        FOR_PASS {
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active && i_choice[s] != RANENV_INTRA_RR && i_nz[s] != 0) {
-                const int row = s * Us, pos = i_pos[u], n = sl_nues(s), n_rbs = i_rbs[s];
-                const double my_val = c_c[row + pos];
-                int m = 0;
-                for16(n, [&](int k, bool ok) { const double v = c_c[row + k]; m += (ok && v != 0.0) ? 1 : 0; });
-                const double tot = np_sum_lds(c_d + row, m, 1);
-                i_cnt[row + pos] = my_val != 0.0 ? (int)((double)n_rbs * my_val / tot) : 0;   // floor of a value >= 0
-            }
-        }
-        __syncthreads();
-        // stage E: hand out the remainder (round_int_equal_sum) or split round-robin
-        FOR_PASS {
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            int my_cnt = 0;
-            if (s >= 0 && any_active) {
-                const int row = s * Us, pos = i_pos[u], n = sl_nues(s), n_rbs = i_rbs[s];
-                const int choice = i_choice[s];
-                if (choice != RANENV_INTRA_RR && i_nz[s] != 0) {
-                    const double my_val = c_c[row + pos];
-                    int acc = 0, m = 0, rank = 0;
-                    for16(n, [&](int k, bool ok) {
-                        const int c = i_cnt[row + k]; const double xk = c_c[row + k];
-                        acc += ok ? c : 0;
-                        m += (ok && xk != 0.0) ? 1 : 0;
-                        rank += (ok && xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0;
-                    });
-                    my_cnt = i_cnt[row + pos];
-                    const int adj = n_rbs - acc;
-                    if (my_val != 0.0 && adj > 0 && m > 0)
-                        my_cnt += adj < m ? (rank < adj ? 1 : 0) : (adj / m + (rank < adj % m ? 1 : 0));
-                } else {
-                    // round_robin: account_buffer only when it is the slice's own choice (:508-555, :609-617)
-                    const bool account = choice == RANENV_INTRA_RR;
-                    int k_sel = 0, idx = 0;
-                    for16(n, [&](int k, bool ok) { const int f = (ok && account) ? i_sel[row + k] : 0; k_sel += f; idx += (k < pos) ? f : 0; });
-                    const bool all = (k_sel == 0);
-                    if (all) { k_sel = n; idx = pos; }
-                    const bool sel = all || i_sel[row + pos] != 0;
-                    const unsigned each = (unsigned)n_rbs / (unsigned)k_sel, rem = (unsigned)n_rbs - each * (unsigned)k_sel;
-                    my_cnt = sel ? (int)(each + ((unsigned)idx < rem ? 1u : 0u)) : 0;
-                }
-            }
-            if (u < U) i_count[u] = my_cnt;
-        }
-        __syncthreads();
-        FOR_PASS {        // counts in slice order for the prefix below
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active) i_cnt[s * Us + i_pos[u]] = i_count[u];
-        }
-        __syncthreads();
-        FOR_PASS {        // :464-478 contiguous ranges
-            const int u = pass * WAVE + lane;
-            const int s = u < U ? i_slice[u] : -1;
-            if (s >= 0 && any_active) {
-                const int row = s * Us, pos = i_pos[u];
-                int start = i_off[s];
-                for16(pos, [&](int k, bool ok) { const int c = i_cnt[row + k]; start += ok ? c : 0; });
-                i_start[u] = start;
-            }
-        }
-        __syncthreads();
+    } else {
+        row_sums(se, R, [](int) { return false; }, se_full, se_part);
     }
-    RANENV_STAMP(4);
+    if (!act) return;
+    const double se_mean_new = se_full / (double)R;
 
-    // ---- P4: every UE's SE row: mean over all RBs and sum over its allocated RBs ------------------
-    // two streams alternate so that the next pass's first loads fly under the current pass's sums
-    auto do_rows = [&](SeStream &st, int u) {
-        double se_full = 0.0, se_part = 0.0;
-        const int uu = u < U ? u : U - 1;                  // idle lanes shadow the last UE (loads stay in bounds)
-        if (RANENV_DIAG == 2) {
-        } else if (MODE == MODE_STEP) {
-            const unsigned ust = (unsigned)i_start[uu], ucn = (unsigned)i_count[uu];
-            row_sums(st, R, [=](int r) { return ((unsigned)r - ust) < ucn; }, se_full, se_part);
-        } else if (MODE == MODE_DENSE) {
-            const uint8_t *mrow = p.dense + ((size_t)b * U + uu) * R;
-            row_sums(st, R, [=](int r) { return mrow[r] != 0; }, se_full, se_part);
-            int cnt = 0, first = 0; bool seen = false;
-            for (int r = 0; r < R; r++) {
-                if (mrow[r] != 0) { cnt++; if (!seen) { first = r; seen = true; } }
-            }
-            if (u < U) { i_count[u] = cnt; i_start[u] = first; }
-        } else {
-            row_sums(st, R, [](int) { return false; }, se_full, se_part);
+    // ---- UEs.step (oracle/ranenv_oracle.c buffer_receive / buffer_send) ---------------------------
+    long long dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;
+    if (MODE != MODE_RESET) {
+        const double psz = (double)pkt_size;
+        // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
+        pkt_thr = (int)((se_part * p.bw_per_rb) / psz);
+        pkt_in = (int)(traffic / psz);
+        const int L = p.L;
+        // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of (arrival TTI,
+        // packets) entries in arrival order.  ring[k] holds entry k of a circular list (head index +
+        // entry count per UE); only TTIs that admitted packets make an entry, so expiring / draining
+        // costs one load per consumed entry and never a scan.
+        int2 *ring = p.st.age_ring + (size_t)e * L * U + u;
+        int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
+        auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
+        auto load_head = [&]() { const int2 en = ring[(size_t)head * U]; front = en.x; front_rem = en.y; };
+        if (nent > 0 && front == t - max_age - 1) {         // receive: the bin older than max_age expires
+            dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
+            front_rem = 0;
+            pop_head();
+            if (nent > 0) load_head();
         }
-        if (u < U) { d_semn[u] = se_full / (double)R; d_part[u] = se_part; }
-    };
+        sum_age += total;                                     // everything left ages one TTI
+        const long long space = (long long)max_pkts - total;  // arrivals admitted up to capacity
+        const long long adm = pkt_in < space ? pkt_in : space;
+        dropped += pkt_in - adm;
+        if (adm > 0) {
+            int tail = head + nent; tail = tail >= L ? tail - L : tail;
+            ring[(size_t)tail * U] = make_int2(t, (int)adm);
+            if (nent == 0) { front = t; front_rem = (int)adm; }
+            nent++;
+            total += (int)adm;
+        }
+        long long cap = pkt_thr;                              // send: drain oldest first
+        while (cap > 0 && nent > 0) {
+            const long long take = cap < front_rem ? cap : front_rem;
+            front_rem -= (int)take; total -= (int)take; cap -= take; sent += take;
+            sum_age -= (long long)(t - front) * take;
+            if (front_rem == 0) {
+                pop_head();
+                if (nent > 0) {
+                    if (nent == 1 && adm > 0) { front = t; front_rem = (int)adm; }   // this TTI's entry
+                    else load_head();
+                }
+            }
+        }
+        fifo = head | (nent << 16);
+    }
+    // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
+    win_sent += sent - old_s; win_drop += dropped - old_d;
+    *rs = (int32_t)sent; *rd = (int32_t)dropped;
+    p.st.queue_pkts[su] = total; p.st.queue_age_sum[su] = sum_age;
+    p.st.front[su] = front; p.st.front_rem[su] = front_rem; p.st.fifo[su] = fifo;
+    p.st.win_sent[su] = win_sent; p.st.win_dropped[su] = win_drop;
+    p.st.se_mean[su] = se_mean_new;
+    p.st.pkt_effective_thr[su] = (int32_t)sent; p.st.dropped_pkts[su] = (int32_t)dropped;
+    if (MODE != MODE_STEP || slc < 0) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
+    if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
+        p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
+    }
+    const double occ_new = (double)total / (double)max_pkts;
+    const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
+
+    // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
+    if (slc >= 0 && has_req) {
+        const double o = p.over;
 #pragma unroll
-    for (int pass = 0; pass < (PASSES > 0 ? PASSES : passes); pass += 2) {
-        const int u0 = pass * WAVE + lane, u1 = u0 + WAVE;
-        if (pass + 1 < passes) se_b.init(tile, U, u1 < U ? u1 : U - 1, R);
-        do_rows(se_a, u0);
-        if (pass + 1 < passes) {
-            const int u2 = u1 + WAVE;
-            if (pass + 2 < passes) se_a.init(tile, U, u2 < U ? u2 : U - 1, R);
-            do_rows(se_b, u1);
-        }
-    }
-    __syncthreads();
-    for (int i = lane; i < S * Us * 3; i += WAVE) d_drift[i] = 0.0;   // shares storage with the P3 rows
-    __syncthreads();
-    RANENV_STAMP(5);
-
-    // ---- P5: UEs.step for every UE (oracle/ranenv_oracle.c buffer_receive/buffer_send) ------------
-    FOR_PASS {
-        const int u = pass * WAVE + lane;
-        if (u < U && RANENV_DIAG != 3) {
-            const size_t su = (size_t)b * U + u;
-            const int pkt_size = i_pkt[u], max_pkts = i_maxp[u], max_age = i_maxage[u];
-            int total = 0, front = 0, front_rem = 0, fifo = 0;
-            long long sum_age = 0, win_sent = 0, win_drop = 0;
-            if (MODE != MODE_RESET) {
-                total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
-                front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
-            }
-            if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
-            // push slot of the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
-            int32_t *rs = p.st.ring_sent + ((size_t)b * D + npush) * U + u;
-            int32_t *rd = p.st.ring_drop + ((size_t)b * D + npush) * U + u;
-            int old_s = 0, old_d = 0;
-            if (hlen == D) { old_s = *rs; old_d = *rd; }
-            long long dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;
-            if (MODE != MODE_RESET) {
-                const double traffic = p.traffic_bits
-                    ? p.traffic_bits[su]
-                    : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
-                const double psz = (double)pkt_size;
-                // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
-                pkt_thr = (int)((d_part[u] * p.bw_per_rb) / psz);
-                pkt_in = (int)(traffic / psz);
-                const int L = p.L;
-                // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of
-                // (arrival TTI, packets) entries in arrival order.  ring[e] holds entry e of a circular
-                // list (head index + entry count per UE); only TTIs that admitted packets make an entry,
-                // so expiring / draining costs one load per consumed entry and never a scan.
-                int2 *ring = p.st.age_ring + (size_t)b * L * U + u;
-                int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
-                auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
-                auto load_head = [&]() { const int2 e = ring[(size_t)head * U]; front = e.x; front_rem = e.y; };
-                // receive_packets: the bin older than max_age expires ...
-                if (nent > 0 && front == t - max_age - 1) {
-                    dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
-                    front_rem = 0;
-                    pop_head();
-                    if (nent > 0) load_head();
+        for (int qi = 0; qi < 3; qi++) {
+            if (qi < npar) {
+                const int metric = pm[qi], op = po[qi];
+                const double value = pv[qi];
+                double res;
+                if (metric == RANENV_METRIC_THROUGHPUT) {
+                    double x = ((double)sent * (double)msg) / 1e6;                  // common.py:25-31
+                    bool zero = d_isclose(occ_new, 0.0);                            // :100-119
+                    if (hlen_new > 1) zero = zero || d_isclose(occ_prev, 0.0);
+                    if (zero) x = value * (1.1 + o);
+                    if (d_apply_op(op, x, value)) res = (x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o);
+                    else res = -((value - x) / value);
+                } else if (metric == RANENV_METRIC_RELIABILITY) {
+                    const double dw = (double)win_drop, sw = (double)win_sent;      // :32-53
+                    const double buffer_pkts = occ_new * (double)bsize + dw + sw;
+                    const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
+                    const double band = (100.0 - value) / 100.0;
+                    if (d_apply_op(op, 100.0 * (1.0 - x), value)) res = (x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o);
+                    else res = -((x - band) / (value / 100.0));
+                } else {
+                    const double x = lat_new;                                       // :58-61
+                    if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
+                    else res = -((x - value) / ((double)blat - value));
                 }
-                sum_age += total;                                   // ... everything left ages one TTI ...
-                const long long space = (long long)max_pkts - total; // ... arrivals admitted up to capacity
-                const long long adm = pkt_in < space ? pkt_in : space;
-                dropped += pkt_in - adm;
-                if (adm > 0) {
-                    int tail = head + nent; tail = tail >= L ? tail - L : tail;
-                    ring[(size_t)tail * U] = make_int2(t, (int)adm);
-                    if (nent == 0) { front = t; front_rem = (int)adm; }
-                    nent++;
-                    total += (int)adm;
-                }
-                // send_packets: drain oldest first
-                long long cap = pkt_thr;
-                while (cap > 0 && nent > 0) {
-                    const long long take = cap < front_rem ? cap : front_rem;
-                    front_rem -= (int)take; total -= (int)take; cap -= take; sent += take;
-                    sum_age -= (long long)(t - front) * take;
-                    if (front_rem == 0) {
-                        pop_head();
-                        if (nent > 0) {
-                            if (nent == 1 && adm > 0) { front = t; front_rem = (int)adm; }   // this TTI's entry
-                            else load_head();
-                        }
-                    }
-                }
-                fifo = head | (nent << 16);
-            }
-            win_sent += sent - old_s; win_drop += dropped - old_d;
-            *rs = (int32_t)sent; *rd = (int32_t)dropped;
-            // state + raw outputs
-            const double se_mean_new = d_semn[u];
-            p.st.queue_pkts[su] = total; p.st.queue_age_sum[su] = sum_age;
-            p.st.front[su] = front; p.st.front_rem[su] = front_rem; p.st.fifo[su] = fifo;
-            p.st.win_sent[su] = win_sent; p.st.win_dropped[su] = win_drop;
-            p.st.se_mean[su] = se_mean_new;
-            p.st.pkt_effective_thr[su] = (int32_t)sent; p.st.dropped_pkts[su] = (int32_t)dropped;
-            if (MODE == MODE_RESET) { i_count[u] = 0; i_start[u] = 0; }
-            p.st.rb_start[su] = i_start[u]; p.st.rb_count[su] = i_count[u];
-            if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
-                p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
-            }
-            const double occ_new = (double)total / (double)max_pkts;
-            const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
-            d_occn[u] = occ_new;
-
-            // intent drift of this UE (agents/common.py:68-340)
-            const int s = i_slice[u];
-            if (s >= 0 && sl_hasreq(s)) {
-                const double o = p.over;
-                const int npar = sl_npar(s), ue_pos = i_pos[u];
-                for (int q = 0; q < npar; q++) {
-                    const int metric = i_par[s * 6 + 2 * q], op = i_par[s * 6 + 2 * q + 1];
-                    const double value = d_par[s * 3 + q];
-                    double res;
-                    if (metric == RANENV_METRIC_THROUGHPUT) {
-                        double x = ((double)sent * (double)sl_msg(s)) / 1e6;           // common.py:25-31
-                        bool zero = d_isclose(occ_new, 0.0);                            // :100-119
-                        if (hlen_new > 1) zero = zero || d_isclose(d_occ[u], 0.0);
-                        if (zero) x = value * (1.1 + o);
-                        if (d_apply_op(op, x, value)) res = (x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o);
-                        else res = -((value - x) / value);
-                    } else if (metric == RANENV_METRIC_RELIABILITY) {
-                        const double dw = (double)win_drop, sw = (double)win_sent;      // :32-53
-                        const double buffer_pkts = occ_new * (double)sl_bsize(s) + dw + sw;
-                        const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
-                        const double band = (100.0 - value) / 100.0;
-                        if (d_apply_op(op, 100.0 * (1.0 - x), value)) res = (x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o);
-                        else res = -((x - band) / (value / 100.0));
-                    } else {
-                        const double x = lat_new;                                       // :58-61
-                        if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
-                        else res = -((x - value) / ((double)sl_blat(s) - value));
-                    }
-                    d_drift[((size_t)s * Us + ue_pos) * 3 + metric] = res;
-                }
+                p.st.drift[su * 3 + metric] = res;
             }
         }
     }
-    __syncthreads();
-    RANENV_STAMP(6);
+    (void)ue_pos;
+}
 
-    // ---- P6: per-slice observation rows, sorted order (ib_sched.py:91-200) ------------------------
-    if (lane < S && RANENV_DIAG != 4) {
-        const int pos = lane;
-        const int s = sl_sorted(pos);
-        const int n = sl_nues(s);
+// =============================================================================================
+// Kernel 3/3  obs: one workgroup = one env, thread = (sorted slice position = tid / 16, UE slot).
+//   calculate_slice_ue_obs agents/common.py:343-378, IBSched.obs_space_format
+//   agents/ib_sched.py:91-200, calculate_reward :206-221 + common.py:381-439, and the per-env
+//   bookkeeping of CommunicationEnv.step (step counter, window length, trace positions, done).
+// =============================================================================================
+template <int MODE>
+__global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
+{
+    __shared__ double rows[GRP][4][GRP];     // per-slice rows: drift x3, mean SE
+    __shared__ double xr[3][GRP];            // cross-slice rows
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
+    const int grp = tid / GRP, slot = tid % GRP;
+    const int S = p.S, U = p.U, Us = p.Us, R = p.R, D = p.D;
+    const int W = 2 * Us + 9;
+    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
+    const bool gok = grp < S;
+
+    int s = 0, active = 0, has_req = 0, n = 0, npar = 0;
+    double priority_tab = 0.0, traffic_tab = 0.0;
+    int pm[3] = {0, 0, 0};
+    if (gok) {
+        s = p.tab.slice_i32[((size_t)sc * S + grp) * 8 + 7];                       // sorted order (:91)
+        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s) * 8;
+        active = si[0]; has_req = si[1]; n = si[2]; npar = si[6];
+        priority_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 0];
+        traffic_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 1];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pm[k] = p.tab.param_i32[(((size_t)sc * S + s) * 3 + k) * 2 + 0];
+    }
+    const bool have = gok && slot < n;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, sem = 0.0, occn = 0.0; int rbc = 0;
+    if (have) {
+        const int ue = p.tab.slice_ues[((size_t)sc * S + s) * Us + slot];
+        const size_t su = (size_t)e * U + ue;
+        d0 = p.st.drift[su * 3 + 0]; d1 = p.st.drift[su * 3 + 1]; d2 = p.st.drift[su * 3 + 2];
+        sem = p.st.se_mean[su];
+        occn = (double)p.st.queue_pkts[su] / (double)p.tab.ue_max_pkts[(size_t)sc * U + ue];
+        rbc = p.st.rb_count[su];
+    }
+    rows[grp][0][slot] = d0; rows[grp][1][slot] = d1; rows[grp][2][slot] = d2; rows[grp][3][slot] = sem;
+    int rbs_alloc = rbc;                                                           // :176-181 (exact integers)
+#pragma unroll
+    for (int d = 1; d < GRP; d <<= 1) rbs_alloc += __shfl_xor(rbs_alloc, d, GRP);
+    // per-UE entries of the intra observation (:186-200)
+    if (gok && p.obs_intra && slot < Us) {
+        float *oa = p.obs_intra + ((size_t)e * S + s) * W;
+        oa[9 + slot] = have ? (float)occn : 0.0f;
+        oa[9 + Us + slot] = have ? (float)(sem / p.norm_se) : 0.0f;
+    }
+    if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
+    __syncthreads();
+    if (gok && slot == 0) {
         double sv[3] = {-2.0, -2.0, -2.0};
-        if (n > 0 && sl_hasreq(s)) {                                  // common.py:343-378
-            const int npar = sl_npar(s);
-            for (int q = 0; q < npar; q++) {
-                const int m = i_par[s * 6 + 2 * q];
-                const double mean = np_sum_lds(d_drift + (size_t)s * Us * 3 + m, n, 3) / (double)n;
-                sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
+        if (n > 0 && has_req) {                                                    // common.py:343-378
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) {
+                if (qi < npar) {
+                    const int m = pm[qi];
+                    const double mean = np_sum16_lds(rows[grp][m], n) / (double)n;
+                    sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
+                }
             }
         }
-        const double traffic_req = sl_active(s) == 1 ? d_slf[s * 2 + 1] : 0.0;
-        const double priority = n != 0 ? d_slf[s * 2 + 0] : 0.0;
+        const double traffic_req = active == 1 ? traffic_tab : 0.0;                // ib_sched.py:125-134
+        const double priority = n != 0 ? priority_tab : 0.0;                       // :135-141
         double am[3];
 #pragma unroll
-        for (int m = 0; m < 3; m++) {
+        for (int m = 0; m < 3; m++) {                                              // :142-145
             const bool undeclared = d_isclose(sv[m], -2.0);
             am[m] = undeclared ? 0.0 : 1.0;
             sv[m] = undeclared ? 0.0 : sv[m];
         }
-        double *se_u = c_d + (size_t)s * Us;
-        double rbs_alloc = 0.0;
-        float *oa = f_obs_intra + (size_t)s * W;
-        for16(Us, [&](int k, bool ok) {
-            const int ue = i_slues[s * Us + k];
-            const bool have = ok && k < n;
-            const int uei = have ? ue : 0;
-            const double sem = d_semn[uei], occn = d_occn[uei];
-            const int cnt = i_count[uei];
-            if (have) { se_u[k] = sem; rbs_alloc += (double)cnt; }
-            if (ok) {
-                oa[9 + k] = have ? (float)occn : 0.0f;
-                oa[9 + Us + k] = have ? (float)(sem / p.norm_se) : 0.0f;
-            }
-        });
-        const double se_slice = n > 0 ? np_sum_lds(se_u, n, 1) / (double)n : 0.0;
-        float *oi = f_obs_inter + pos * 10;
-        oi[0] = (float)sv[0]; oi[1] = (float)sv[1]; oi[2] = (float)sv[2];
-        oi[3] = (float)am[0]; oi[4] = (float)am[1]; oi[5] = (float)am[2];
-        oi[6] = (float)priority; oi[7] = (float)(traffic_req / p.norm_traffic);
-        oi[8] = (float)((double)n / p.norm_ues); oi[9] = (float)(se_slice / p.norm_se);
-        oa[0] = oi[0]; oa[1] = oi[1]; oa[2] = oi[2]; oa[3] = oi[3]; oa[4] = oi[4]; oa[5] = oi[5];
-        oa[6] = (float)(rbs_alloc / (double)R); oa[7] = oi[7]; oa[8] = oi[8];
-        // float64 values for the reward (calculate_reward reads the same numbers), indexed by slice
-        double mn = 0.0; int cntm = 0;                              // common.py:400-407
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-            const double v = sv[m];
-            if (!d_isclose(v, -2.0)) { mn = (cntm == 0 || v < mn) ? v : mn; cntm++; }
+        const double se_slice = n > 0 ? np_sum16_lds(rows[grp][3], n) / (double)n : 0.0;   // :146-157
+        const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
+        const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
+        const float tr = (float)(traffic_req / p.norm_traffic), nu = (float)((double)n / p.norm_ues);
+        if (p.obs_inter) {                                                         // :160-173
+            float *oi = p.obs_inter + ((size_t)e * S + grp) * 10;
+            oi[0] = o0; oi[1] = o1; oi[2] = o2; oi[3] = a0; oi[4] = a1; oi[5] = a2;
+            oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)(se_slice / p.norm_se);
         }
-        d_slvals[s] = sl_active(s) ? (cntm > 0 ? mn : 1.0) : 0.0;   // active_observations[s]
-        d_slflags[s] = sl_active(s) ? d_slf[s * 2 + 0] : 0.0;        // slice_priorities[s]
+        if (p.obs_intra) {
+            float *oa = p.obs_intra + ((size_t)e * S + s) * W;
+            oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
+            oa[6] = (float)((double)rbs_alloc / (double)R); oa[7] = tr; oa[8] = nu;
+        }
         // player_{s+1} reward (common.py:428-437)
         double r = 0.0; int cnt = 0;
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             if (am[m] > 0.0) { r = (cnt == 0 || sv[m] < r) ? sv[m] : r; cnt++; }
         }
-        if (p.reward) p.reward[(size_t)b * (S + 1) + s + 1] = cnt > 0 ? r : 0.0;
+        if (p.reward) p.reward[(size_t)e * (S + 1) + s + 1] = cnt > 0 ? r : 0.0;
         if (MODE == MODE_RESET) {
-            p.st.mask_inter[(size_t)b * S + s] = (int8_t)sl_active(s);
-            for (int k = 0; k < Us; k++) p.st.mask_intra[((size_t)b * S + s) * Us + k] = k < n ? 1 : 0;
+            p.st.mask_inter[(size_t)e * S + s] = (int8_t)active;
+            for (int k = 0; k < Us; k++) p.st.mask_intra[((size_t)e * S + s) * Us + k] = k < n ? 1 : 0;
         }
+        // active_observations / slice_priorities indexed by slice (common.py:389-408)
+        double mn = 0.0; int cntm = 0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const double v = sv[m];
+            if (!d_isclose(v, -2.0)) { mn = (cntm == 0 || v < mn) ? v : mn; cntm++; }
+        }
+        xr[0][s] = active ? (cntm > 0 ? mn : 1.0) : 0.0;
+        xr[1][s] = active ? priority_tab : 0.0;
     }
     __syncthreads();
-    RANENV_STAMP(7);
-
-    // ---- P7: player_0 reward (common.py:389-427 after unsort_slices, ib_sched.py:372-392) ----------
-    if (RANENV_DIAG != 4) {
-        // every lane evaluates the (cheap, uniform) selection logic; lane 0 stores
+    // ---- player_0 reward (common.py:409-427), threads 0..15 = slices ------------------------------
+    bool my_sel = false; int m_sel = 0, cslot = 0, mode_sel = 0; double my_ao = 0.0;
+    if (tid < GRP) {
         int n_neg = 0, n_prio_neg = 0;
-        for16(S, [&](int s, bool ok) {
-            const double ao = d_slvals[s], pr = d_slflags[s];
-            n_neg += (ok && ao < 0.0) ? 1 : 0;
-            n_prio_neg += (ok && pr * ao < 0.0) ? 1 : 0;
-        });
-        // compact the selected entries in slice order (np.mean over the boolean-indexed array)
-        const int mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
-        bool mine = false; int slot = 0, m = 0;
-        for16(S, [&](int s, bool ok) {
-            const double ao = d_slvals[s], pr = d_slflags[s];
-            const bool sel = ok && (mode_sel == 0 ? true : (mode_sel == 1 ? (ao * pr < 0.0) : (ao < 0.0)));
-            m += sel ? 1 : 0; slot += (sel && s < lane) ? 1 : 0;
-            mine = (s == lane) ? sel : mine;
-        });
-        if (lane < S && mine) d_tmp[slot] = d_slvals[lane];
-        __syncthreads();
-        if (lane == 0) {
-            double rew = np_sum_lds(d_tmp, m, 1) / (double)m;
-            if (mode_sel == 1) rew -= 1.0;
-            if (p.reward) p.reward[(size_t)b * (S + 1)] = rew;
-            const int step_new = (MODE == MODE_RESET) ? 0 : step + 1;
-            p.st.step_no[b] = step_new;
-            p.st.hist_len[b] = hlen_new;
-            p.st.n_push[b] = npush + 1 == D ? 0 : npush + 1;
-            if (MODE == MODE_RESET) { p.st.se_pos[b] = se_pos; p.st.trf_pos[b] = trf_pos; }
-            else {
-                p.st.se_pos[b] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
-                p.st.trf_pos[b] = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
-            }
-            if (p.done) p.done[b] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double ao = xr[0][j], pr = xr[1][j];
+            n_neg += (j < S && ao < 0.0) ? 1 : 0;
+            n_prio_neg += (j < S && pr * ao < 0.0) ? 1 : 0;
         }
+        mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
+        my_ao = xr[0][tid];
+        const double my_pr = xr[1][tid];
+        my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
+        const unsigned gm = (unsigned)(__ballot(my_sel) & 0xffffull);
+        m_sel = __popc(gm); cslot = __popc(gm & ((1u << tid) - 1u));
+        xr[2][tid] = 0.0;
     }
-    RANENV_STAMP(8);
-    if (RANENV_DIAG == 9 && MODE == MODE_STEP && lane == 0 && S >= 9) {
-        for (int k = 0; k < 9; k++) p.st.policy_scores[(size_t)b * S + k] = (double)(stamps[k] - stamps[0]);
+    __syncthreads();
+    if (my_sel) xr[2][cslot] = my_ao;             // selected entries in slice order (np.mean of a[mask])
+    __syncthreads();
+    if (tid == 0) {
+        double rew = np_sum16_lds(xr[2], m_sel) / (double)m_sel;
+        if (mode_sel == 1) rew -= 1.0;
+        if (p.reward) p.reward[(size_t)e * (S + 1)] = rew;
+        const ranenv_episode ep = p.episodes[e];
+        const int hlen0 = (MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET)) ? 0 : p.st.hist_len[e];
+        const int npush = p.st.n_push[e];
+        const int step_new = (MODE == MODE_RESET) ? 0 : p.st.step_no[e] + 1;
+        p.st.step_no[e] = step_new;
+        p.st.hist_len[e] = hlen0 < D ? hlen0 + 1 : D;
+        p.st.n_push[e] = npush + 1 == D ? 0 : npush + 1;
+        if (MODE == MODE_RESET) { p.st.se_pos[e] = ep.se_offset; p.st.trf_pos[e] = ep.trf_offset; }
+        else {
+            const int sp = p.st.se_pos[e], tp = p.st.trf_pos[e];
+            p.st.se_pos[e] = sp + 1 >= ep.se_len ? 0 : sp + 1;
+            p.st.trf_pos[e] = tp + 1 >= ep.trf_len ? 0 : tp + 1;
+        }
+        if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
     }
-    if (p.obs_inter) for (int i = lane; i < S * 10; i += WAVE) p.obs_inter[(size_t)b * S * 10 + i] = f_obs_inter[i];
-    if (p.obs_intra) for (int i = lane; i < S * W; i += WAVE) p.obs_intra[(size_t)b * S * W + i] = f_obs_intra[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1019,31 +866,27 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
 }
 
 template <int MODE>
+void launch_core(ranenv_handle h, const KP &kp, hipStream_t stream)
+{
+    const dim3 grid(kp.B), block(h->nt);
+    switch (h->nt) {
+    case 64:   hipLaunchKernelGGL((ranenv_core_kernel<MODE, 64>), grid, block, 0, stream, kp); break;
+    case 128:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 128>), grid, block, 0, stream, kp); break;
+    case 256:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 256>), grid, block, 0, stream, kp); break;
+    case 512:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 512>), grid, block, 0, stream, kp); break;
+    default:   hipLaunchKernelGGL((ranenv_core_kernel<MODE, 1024>), grid, block, 0, stream, kp); break;
+    }
+}
+
+// One TTI = alloc -> core -> obs on one stream (reset / dense skip the alloc kernel).
+template <int MODE>
 hipError_t launch(ranenv_handle h, const KP &kp, hipStream_t stream)
 {
-    const dim3 grid(kp.B), block(WAVE);
-    const size_t lds = (size_t)h->lds_bytes;
-    const int passes = (kp.U + WAVE - 1) / WAVE;
-    if (passes == 1) hipLaunchKernelGGL((ranenv_kernel<MODE, 1>), grid, block, lds, stream, kp);
-    else if (passes == 2) hipLaunchKernelGGL((ranenv_kernel<MODE, 2>), grid, block, lds, stream, kp);
-    else hipLaunchKernelGGL((ranenv_kernel<MODE, 0>), grid, block, lds, stream, kp);
+    if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(kp.B), dim3(ALLOC_NT), 0, stream, kp);
+    launch_core<MODE>(h, kp, stream);
+    if (MODE == MODE_RESET) hipLaunchKernelGGL((ranenv_obs_kernel<MODE_RESET>), dim3(kp.B), dim3(ALLOC_NT), 0, stream, kp);
+    else hipLaunchKernelGGL((ranenv_obs_kernel<MODE_STEP>), dim3(kp.B), dim3(ALLOC_NT), 0, stream, kp);
     return hipGetLastError();
-}
-
-template <int MODE, int PASSES>
-hipError_t set_lds_attr1(int bytes)
-{
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&ranenv_kernel<MODE, PASSES>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-
-template <int MODE>
-hipError_t set_lds_attr(int bytes)
-{
-    hipError_t e = set_lds_attr1<MODE, 1>(bytes);
-    if (e == hipSuccess) e = set_lds_attr1<MODE, 2>(bytes);
-    if (e == hipSuccess) e = set_lds_attr1<MODE, 0>(bytes);
-    return e;
 }
 
 }  // namespace
@@ -1059,11 +902,11 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     *out = nullptr;
     if (cfg->abi_version != RANENV_ABI_VERSION) return fail(nullptr, RANENV_E_INVALID, "abi_version %d != %d", cfg->abi_version, RANENV_ABI_VERSION);
     const int S = cfg->n_slices, U = cfg->n_ues, R = cfg->n_rbs, Us = cfg->max_ues_slice;
-    if (cfg->batch < 1 || S < 1 || S > 64 || U < 1 || U > 1024 || R < 1 || R > 512 || Us < 1 || Us > 128 ||
+    if (cfg->batch < 1 || S < 1 || S > GRP || U < 1 || U > 1024 || R < 1 || R > 512 || Us < 1 || Us > GRP ||
         cfg->rbs_per_rbg < 1 || cfg->rbs_per_rbg > R || cfg->hist_depth < 1 || cfg->hist_depth > 64 ||
         cfg->max_age_cap < 1 || cfg->max_age_cap > 65000 || cfg->max_steps < 1 || cfg->n_scenarios < 1)
         return fail(nullptr, RANENV_E_INVALID,
-                    "unsupported sizes: need 1<=S<=64, 1<=U<=1024, 1<=R<=512, 1<=Us<=128, 1<=G<=R, 1<=hist_depth<=64");
+                    "unsupported sizes: need 1<=S<=16, 1<=U<=1024, 1<=R<=512, 1<=Us<=16, 1<=G<=R, 1<=hist_depth<=64");
     if (!(cfg->bandwidth_hz > 0.0)) return fail(nullptr, RANENV_E_INVALID, "bandwidth_hz must be positive");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1098,19 +941,20 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.st.pkt_incoming, B * U); ALLOC(kp.st.pkt_throughputs, B * U); ALLOC(kp.st.pkt_effective_thr, B * U);
     ALLOC(kp.st.dropped_pkts, B * U); ALLOC(kp.st.rb_start, B * U); ALLOC(kp.st.rb_count, B * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
+    ALLOC(kp.st.drift, B * U * 3);
     ALLOC(h->d_episodes, B);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
-    h->nt = WAVE;
-    h->lds_bytes = make_layout(S, U, Us).total;
-    if (h->lds_bytes > 160 * 1024) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "LDS need %d B exceeds 160 KiB", h->lds_bytes); }
-    e = set_lds_attr<MODE_STEP>(h->lds_bytes);
-    if (e == hipSuccess) e = set_lds_attr<MODE_DENSE>(h->lds_bytes);
-    if (e == hipSuccess) e = set_lds_attr<MODE_RESET>(h->lds_bytes);
-    if (e != hipSuccess) {
-        ranenv_destroy(h);
-        return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncSetAttribute: %s)", hipGetErrorString(e));
+    h->nt = U <= 64 ? 64 : U <= 128 ? 128 : U <= 256 ? 256 : U <= 512 ? 512 : 1024;
+    h->lds_bytes = GRP * 4 * GRP * 8 + 3 * GRP * 8;   // static LDS of the widest kernel (obs)
+    {   // fail at create, not at the first step, when the code object has no gfx950 image
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_alloc_kernel));
+        if (e != hipSuccess) {
+            ranenv_destroy(h);
+            return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
+        }
     }
     *out = h;
     return RANENV_OK;
