@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -58,6 +59,7 @@ struct Tables {  // scenario pool on the device, rows of [n_scenarios]
     int32_t *param_i32;  // [NS][S][3][2] metric, op
     double  *param_f64;  // [NS][S][3]
     int32_t *slice_ues;  // [NS][S][Us]
+    int32_t *slot_ue, *slot_mp, *slot_pk;   // [NS][S*16] UE id (-1 = empty slot), its max_pkts / pkt_size
     int32_t *ue_slice, *ue_pos, *ue_pkt_size, *ue_max_pkts, *ue_max_age;  // [NS][U]
 };
 
@@ -68,11 +70,14 @@ struct State {
     int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
     int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
-    double *drift;              // [B][U][3] per-UE intent drift, core -> obs
+    // slot-ordered records, slot = slice*16 + position: written by core (alloc for rbc), read
+    // coalesced by alloc and obs                                         [B][S*16]
+    int32_t *slot_q; int64_t *slot_ws; double *slot_sem; double *slot_d0, *slot_d1, *slot_d2; int32_t *slot_rbc;
 };
 
 struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
+    int e0;   // first env of this launch (the batch is stepped in chunks on parallel streams)
     double bw_hz, bw_per_rb, over, norm_traffic, norm_ues, norm_se;
     Tables tab;
     State st;
@@ -110,13 +115,20 @@ DEVFN double np_sum16(const double (&xin)[16], int n)
     return n < 8 ? seq : (n < 16 ? t8 : t16);
 }
 
-// the same over a row of 16 doubles in LDS (all 16 reads issue back to back)
+// the same over a row of 16 doubles in LDS whose entries at positions >= n are +0.0 (every writer
+// in this file zero-pads its rows), so no per-element select is needed; all 16 reads issue back to back
 DEVFN double np_sum16_lds(const double *row, int n)
 {
     double x[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = row[j];
-    return np_sum16(x, n);
+    const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
+    double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+#pragma unroll
+    for (int j = 8; j < 15; j++) t8 += x[j];
+    const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
+                       (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
+    return n < 8 ? seq : (n < 16 ? t8 : t16);
 }
 
 DEVFN bool d_apply_op(int op, double a, double b)
@@ -285,24 +297,25 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
     __shared__ double xs[4][GRP];            // cross-slice rows
     __shared__ double rows[GRP][2][GRP];     // per-slice rows
     __shared__ int sh_rbs[GRP], sh_off[GRP];
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
     const int s = tid / GRP, pos = tid % GRP;          // intra role: (slice, UE slot)
-    const int S = p.S, U = p.U, Us = p.Us;
+    const int S = p.S, U = p.U;
     const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
     const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
     double *ra = rows[s][0], *rb = rows[s][1];
 
-    // ---- this thread's UE (slot pos of slice s) ------------------------------------------------
-    int n = 0;
-    if (s < S) n = p.tab.slice_i32[((size_t)sc * S + s) * 8 + 2];
-    const bool have = s < S && pos < n;
-    int ue = 0, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
-    if (have) {
-        ue = p.tab.slice_ues[((size_t)sc * S + s) * Us + pos];
-        q = p.st.queue_pkts[(size_t)e * U + ue]; wsent = p.st.win_sent[(size_t)e * U + ue];
-        sem = p.st.se_mean[(size_t)e * U + ue];
-        mp = p.tab.ue_max_pkts[(size_t)sc * U + ue]; pk = p.tab.ue_pkt_size[(size_t)sc * U + ue];
+    // ---- this thread's UE: slot tid of the env's slot-ordered records (coalesced, one level) ------
+    const int NS16 = S * GRP;
+    const bool in_grid = tid < NS16;
+    int ue = -1, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
+    if (in_grid) {
+        const size_t ts = (size_t)sc * NS16 + tid, es = (size_t)e * NS16 + tid;
+        ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; pk = p.tab.slot_pk[ts];
+        q = p.st.slot_q[es]; wsent = p.st.slot_ws[es]; sem = p.st.slot_sem[es];
     }
+    const bool have = ue >= 0;
+    const int gsh = (tid & 63) & ~(GRP - 1);
+    const int n = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));   // UEs of this slice
     const double occ = (double)q / (double)mp;
     const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
     const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
@@ -420,7 +433,6 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
     const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
     const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
     const bool nzv = my_val != 0.0;
-    const int gsh = (tid & 63) & ~(GRP - 1);
     const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
     const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
     __syncthreads();
@@ -463,6 +475,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
         p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
         p.st.rb_count[(size_t)e * U + ue] = count;
     }
+    if (in_grid) p.st.slot_rbc[(size_t)e * NS16 + tid] = count;
 }
 
 // =============================================================================================
@@ -474,7 +487,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 template <int MODE, int NT>
 __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
 {
-    const int e = blockIdx.x;
+    const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
     if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
     const int S = p.S, U = p.U, R = p.R, D = p.D;
@@ -528,20 +541,6 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
     double traffic = 0.0;
     if (MODE != MODE_RESET)
         traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
-    // slice row for the drift (agents/common.py:9-65 needs message_size, buffer_size, buffer_latency)
-    int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
-    int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
-    double pv[3] = {0.0, 0.0, 0.0};
-    if (slc >= 0) {
-        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
-        has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
-            po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
-            pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
-        }
-    }
     const double occ_prev = (double)total / (double)max_pkts;
 
     // ---- this UE's SE row: mean over all RBs and sum over its allocated RBs ----------------------
@@ -561,6 +560,21 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
     }
     if (!act) return;
     const double se_mean_new = se_full / (double)R;
+    // slice row for the drift: L2-resident table reads, issued after the row loop to keep its
+    // register footprint small (agents/common.py:9-65 needs message_size, buffer_size, buffer_latency)
+    int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
+    int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
+    double pv[3] = {0.0, 0.0, 0.0};
+    if (slc >= 0) {
+        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
+        has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
+            po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
+            pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
+        }
+    }
 
     // ---- UEs.step (oracle/ranenv_oracle.c buffer_receive / buffer_send) ---------------------------
     long long dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;
@@ -626,6 +640,7 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
     const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
 
     // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
+    double dres[3] = {0.0, 0.0, 0.0};
     if (slc >= 0 && has_req) {
         const double o = p.over;
 #pragma unroll
@@ -653,11 +668,16 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
                     if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
                     else res = -((x - value) / ((double)blat - value));
                 }
-                p.st.drift[su * 3 + metric] = res;
+                dres[metric] = res;
             }
         }
     }
-    (void)ue_pos;
+    if (slc >= 0) {   // slot-ordered record for alloc (next TTI) and obs (this TTI)
+        const size_t es = (size_t)e * (S * GRP) + slc * GRP + ue_pos;
+        p.st.slot_q[es] = total; p.st.slot_ws[es] = win_sent; p.st.slot_sem[es] = se_mean_new;
+        p.st.slot_d0[es] = dres[0]; p.st.slot_d1[es] = dres[1]; p.st.slot_d2[es] = dres[2];
+        if (MODE != MODE_STEP) p.st.slot_rbc[es] = rb_count;
+    }
 }
 
 // =============================================================================================
@@ -669,58 +689,61 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
 template <int MODE>
 __global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
 {
-    __shared__ double rows[GRP][4][GRP];     // per-slice rows: drift x3, mean SE
+    __shared__ double rows[GRP][4][GRP];     // per-slice rows (by slice index): drift x3, mean SE
     __shared__ double xr[3][GRP];            // cross-slice rows
-    const int e = blockIdx.x, tid = threadIdx.x;
+    __shared__ int sh_n[GRP], sh_rbs[GRP];
+    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
     if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
-    const int grp = tid / GRP, slot = tid % GRP;
-    const int S = p.S, U = p.U, Us = p.Us, R = p.R, D = p.D;
-    const int W = 2 * Us + 9;
+    const int S = p.S, Us = p.Us, R = p.R, D = p.D;
+    const int W = 2 * Us + 9, NS16 = S * GRP;
     const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
-    const bool gok = grp < S;
-
-    int s = 0, active = 0, has_req = 0, n = 0, npar = 0;
-    double priority_tab = 0.0, traffic_tab = 0.0;
-    int pm[3] = {0, 0, 0};
-    if (gok) {
-        s = p.tab.slice_i32[((size_t)sc * S + grp) * 8 + 7];                       // sorted order (:91)
-        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s) * 8;
-        active = si[0]; has_req = si[1]; n = si[2]; npar = si[6];
-        priority_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 0];
-        traffic_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 1];
-#pragma unroll
-        for (int k = 0; k < 3; k++) pm[k] = p.tab.param_i32[(((size_t)sc * S + s) * 3 + k) * 2 + 0];
+    // ---- every thread: one slot of the env's slot-ordered records (coalesced) ---------------------
+    const int sl = tid / GRP, pos = tid % GRP;              // (slice, position)
+    const bool in_grid = tid < NS16;
+    int ue = -1, q = 0, mp = 1, rbc = 0; double d0 = 0.0, d1 = 0.0, d2 = 0.0, sem = 0.0;
+    if (in_grid) {
+        const size_t ts = (size_t)sc * NS16 + tid, es = (size_t)e * NS16 + tid;
+        ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts];
+        q = p.st.slot_q[es]; sem = p.st.slot_sem[es]; rbc = p.st.slot_rbc[es];
+        d0 = p.st.slot_d0[es]; d1 = p.st.slot_d1[es]; d2 = p.st.slot_d2[es];
     }
-    const bool have = gok && slot < n;
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0, sem = 0.0, occn = 0.0; int rbc = 0;
-    if (have) {
-        const int ue = p.tab.slice_ues[((size_t)sc * S + s) * Us + slot];
-        const size_t su = (size_t)e * U + ue;
-        d0 = p.st.drift[su * 3 + 0]; d1 = p.st.drift[su * 3 + 1]; d2 = p.st.drift[su * 3 + 2];
-        sem = p.st.se_mean[su];
-        occn = (double)p.st.queue_pkts[su] / (double)p.tab.ue_max_pkts[(size_t)sc * U + ue];
-        rbc = p.st.rb_count[su];
-    }
-    rows[grp][0][slot] = d0; rows[grp][1][slot] = d1; rows[grp][2][slot] = d2; rows[grp][3][slot] = sem;
-    int rbs_alloc = rbc;                                                           // :176-181 (exact integers)
+    const bool have = ue >= 0;
+    rows[sl][0][pos] = have ? d0 : 0.0; rows[sl][1][pos] = have ? d1 : 0.0;
+    rows[sl][2][pos] = have ? d2 : 0.0; rows[sl][3][pos] = have ? sem : 0.0;
+    const int gsh = (tid & 63) & ~(GRP - 1);
+    const int n_grp = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));
+    int rsum = have ? rbc : 0;                                                     // :176-181 (exact integers)
 #pragma unroll
-    for (int d = 1; d < GRP; d <<= 1) rbs_alloc += __shfl_xor(rbs_alloc, d, GRP);
-    // per-UE entries of the intra observation (:186-200)
-    if (gok && p.obs_intra && slot < Us) {
-        float *oa = p.obs_intra + ((size_t)e * S + s) * W;
-        oa[9 + slot] = have ? (float)occn : 0.0f;
-        oa[9 + Us + slot] = have ? (float)(sem / p.norm_se) : 0.0f;
+    for (int d = 1; d < GRP; d <<= 1) rsum += __shfl_xor(rsum, d, GRP);
+    if (pos == 0) { sh_n[sl] = n_grp; sh_rbs[sl] = rsum; }
+    if (in_grid && p.obs_intra && pos < Us) {                                      // per-UE entries (:186-200)
+        float *oa = p.obs_intra + ((size_t)e * S + sl) * W;
+        oa[9 + pos] = have ? (float)((double)q / (double)mp) : 0.0f;
+        oa[9 + Us + pos] = have ? (float)(sem / p.norm_se) : 0.0f;
     }
     if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
     __syncthreads();
-    if (gok && slot == 0) {
-        double sv[3] = {-2.0, -2.0, -2.0};
+    if (tid >= GRP) return;                  // the per-slice rows are done by threads 0..15 (one wave)
+
+    // ---- thread t < 16: slice at sorted position t (ib_sched.py:91) --------------------------------
+    const int spos = tid;
+    const bool ok = spos < S;
+    double sv[3] = {-2.0, -2.0, -2.0};
+    int s = 0, active = 0;
+    double priority_tab = 0.0;
+    if (ok) {
+        s = p.tab.slice_i32[((size_t)sc * S + spos) * 8 + 7];
+        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s) * 8;
+        active = si[0];
+        const int has_req = si[1], npar = si[6], n = sh_n[s];
+        priority_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 0];
+        const double traffic_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 1];
         if (n > 0 && has_req) {                                                    // common.py:343-378
 #pragma unroll
             for (int qi = 0; qi < 3; qi++) {
                 if (qi < npar) {
-                    const int m = pm[qi];
-                    const double mean = np_sum16_lds(rows[grp][m], n) / (double)n;
+                    const int m = p.tab.param_i32[(((size_t)sc * S + s) * 3 + qi) * 2 + 0];
+                    const double mean = np_sum16_lds(rows[s][m], n) / (double)n;
                     sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
                 }
             }
@@ -734,19 +757,20 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
             am[m] = undeclared ? 0.0 : 1.0;
             sv[m] = undeclared ? 0.0 : sv[m];
         }
-        const double se_slice = n > 0 ? np_sum16_lds(rows[grp][3], n) / (double)n : 0.0;   // :146-157
+        const double se_slice = n > 0 ? np_sum16_lds(rows[s][3], n) / (double)n : 0.0;   // :146-157
         const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
         const float tr = (float)(traffic_req / p.norm_traffic), nu = (float)((double)n / p.norm_ues);
         if (p.obs_inter) {                                                         // :160-173
-            float *oi = p.obs_inter + ((size_t)e * S + grp) * 10;
+            float *oi = p.obs_inter + ((size_t)e * S + spos) * 10;
             oi[0] = o0; oi[1] = o1; oi[2] = o2; oi[3] = a0; oi[4] = a1; oi[5] = a2;
             oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)(se_slice / p.norm_se);
         }
         if (p.obs_intra) {
             float *oa = p.obs_intra + ((size_t)e * S + s) * W;
             oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
-            oa[6] = (float)((double)rbs_alloc / (double)R); oa[7] = tr; oa[8] = nu;
+            oa[6] = (float)((double)sh_rbs[s] / (double)R); oa[7] = tr; oa[8] = nu;
+            for (int k = GRP; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
         }
         // player_{s+1} reward (common.py:428-437)
         double r = 0.0; int cnt = 0;
@@ -769,28 +793,26 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
         xr[0][s] = active ? (cntm > 0 ? mn : 1.0) : 0.0;
         xr[1][s] = active ? priority_tab : 0.0;
     }
-    __syncthreads();
-    // ---- player_0 reward (common.py:409-427), threads 0..15 = slices ------------------------------
-    bool my_sel = false; int m_sel = 0, cslot = 0, mode_sel = 0; double my_ao = 0.0;
-    if (tid < GRP) {
-        int n_neg = 0, n_prio_neg = 0;
+    // only one wave is left: LDS traffic between its lanes needs an LDS wait, not a barrier
+    auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    wave_sync();
+    // ---- player_0 reward (common.py:409-427) ------------------------------------------------------
+    int n_neg = 0, n_prio_neg = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const double ao = xr[0][j], pr = xr[1][j];
-            n_neg += (j < S && ao < 0.0) ? 1 : 0;
-            n_prio_neg += (j < S && pr * ao < 0.0) ? 1 : 0;
-        }
-        mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
-        my_ao = xr[0][tid];
-        const double my_pr = xr[1][tid];
-        my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
-        const unsigned gm = (unsigned)(__ballot(my_sel) & 0xffffull);
-        m_sel = __popc(gm); cslot = __popc(gm & ((1u << tid) - 1u));
-        xr[2][tid] = 0.0;
+    for (int j = 0; j < 16; j++) {
+        const double ao = xr[0][j], pr = xr[1][j];
+        n_neg += (j < S && ao < 0.0) ? 1 : 0;
+        n_prio_neg += (j < S && pr * ao < 0.0) ? 1 : 0;
     }
-    __syncthreads();
+    const int mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
+    const double my_ao = xr[0][tid], my_pr = xr[1][tid];
+    const bool my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
+    const unsigned gm = (unsigned)(__ballot(my_sel) & 0xffffull);
+    const int m_sel = __popc(gm), cslot = __popc(gm & ((1u << tid) - 1u));
+    xr[2][tid] = 0.0;
+    wave_sync();
     if (my_sel) xr[2][cslot] = my_ao;             // selected entries in slice order (np.mean of a[mask])
-    __syncthreads();
+    wave_sync();
     if (tid == 0) {
         double rew = np_sum16_lds(xr[2], m_sel) / (double)m_sel;
         if (mode_sel == 1) rew -= 1.0;
@@ -827,6 +849,19 @@ struct ranenv {
     bool have_scenarios = false, have_episodes = false;
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
     int nt = 0, lds_bytes = 0;
+    // the batch is stepped as n_chunks independent sub-batches on parallel streams, so that the
+    // latency-bound alloc/obs kernels of one chunk overlap the bandwidth-bound core kernel of another
+    static constexpr int MAX_CHUNKS = 16;
+    int n_chunks = 1;
+    hipStream_t aux[MAX_CHUNKS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHUNKS] = {};
+    hipStream_t main_stream = nullptr;          // used when the caller hands over the null stream,
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // which cannot be captured
+    // replay cache: a launch sequence whose arguments repeat is captured once into a hipGraph
+    struct Cached { bool used = false; int mode = -1; int seen = 0; KP kp; hipGraphExec_t exec = nullptr; };
+    Cached cache[6];
+    int cache_next = 0;
+    bool use_graph = true;
     std::string err;
 };
 
@@ -866,9 +901,9 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
 }
 
 template <int MODE>
-void launch_core(ranenv_handle h, const KP &kp, hipStream_t stream)
+void launch_core(ranenv_handle h, const KP &kp, int n_env, hipStream_t stream)
 {
-    const dim3 grid(kp.B), block(h->nt);
+    const dim3 grid(n_env), block(h->nt);
     switch (h->nt) {
     case 64:   hipLaunchKernelGGL((ranenv_core_kernel<MODE, 64>), grid, block, 0, stream, kp); break;
     case 128:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 128>), grid, block, 0, stream, kp); break;
@@ -878,15 +913,103 @@ void launch_core(ranenv_handle h, const KP &kp, hipStream_t stream)
     }
 }
 
-// One TTI = alloc -> core -> obs on one stream (reset / dense skip the alloc kernel).
+// One TTI of envs [e0, e0 + n_env) = alloc -> core -> obs on one stream (reset / dense skip alloc).
+template <int MODE>
+void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
+{
+    kp.e0 = e0;
+    const dim3 sblock((unsigned)(((kp.S * GRP) + WAVE - 1) / WAVE * WAVE));   // one thread per slot
+    if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
+    launch_core<MODE>(h, kp, n_env, stream);
+    if (MODE == MODE_RESET) hipLaunchKernelGGL((ranenv_obs_kernel<MODE_RESET>), dim3(n_env), sblock, 0, stream, kp);
+    else hipLaunchKernelGGL((ranenv_obs_kernel<MODE_STEP>), dim3(n_env), sblock, 0, stream, kp);
+}
+
+// Fork the caller's stream into the chunk streams and join them back.
+template <int MODE>
+hipError_t enqueue(ranenv_handle h, const KP &kp, hipStream_t stream)
+{
+    const int nc = h->n_chunks;
+    if (nc <= 1) {
+        launch_chunk<MODE>(h, kp, 0, kp.B, stream);
+        return hipGetLastError();
+    }
+    hipError_t e = hipEventRecord(h->ev_fork, stream);
+    if (e != hipSuccess) return e;
+    const int per = (kp.B + nc - 1) / nc;
+    for (int c = 0; c < nc; c++) {
+        const int e0 = c * per, n_env = (e0 + per <= kp.B) ? per : kp.B - e0;
+        if (n_env <= 0) break;
+        e = hipStreamWaitEvent(h->aux[c], h->ev_fork, 0);
+        if (e != hipSuccess) return e;
+        launch_chunk<MODE>(h, kp, e0, n_env, h->aux[c]);
+        e = hipEventRecord(h->ev_join[c], h->aux[c]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_join[c], 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+// Launch with replay: the second time an identical argument block shows up, the sequence is
+// captured into a hipGraph; from then on it is replayed with one hipGraphLaunch.
+template <int MODE>
+hipError_t launch_on(ranenv_handle h, const KP &kp, hipStream_t stream);
+
 template <int MODE>
 hipError_t launch(ranenv_handle h, const KP &kp, hipStream_t stream)
 {
-    if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(kp.B), dim3(ALLOC_NT), 0, stream, kp);
-    launch_core<MODE>(h, kp, stream);
-    if (MODE == MODE_RESET) hipLaunchKernelGGL((ranenv_obs_kernel<MODE_RESET>), dim3(kp.B), dim3(ALLOC_NT), 0, stream, kp);
-    else hipLaunchKernelGGL((ranenv_obs_kernel<MODE_STEP>), dim3(kp.B), dim3(ALLOC_NT), 0, stream, kp);
-    return hipGetLastError();
+    if (stream != nullptr || !h->use_graph || h->main_stream == nullptr) return launch_on<MODE>(h, kp, stream);
+    // the legacy null stream cannot be captured: run on the handle's own stream, ordered after the
+    // caller's earlier work and before its later work
+    hipError_t e = hipEventRecord(h->ev_in, stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->main_stream, h->ev_in, 0);
+    if (e == hipSuccess) e = launch_on<MODE>(h, kp, h->main_stream);
+    if (e == hipSuccess) e = hipEventRecord(h->ev_out, h->main_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_out, 0);
+    return e;
+}
+
+template <int MODE>
+hipError_t launch_on(ranenv_handle h, const KP &kp, hipStream_t stream)
+{
+    if (!h->use_graph) return enqueue<MODE>(h, kp, stream);
+    ranenv::Cached *hit = nullptr;
+    for (auto &c : h->cache)
+        if (c.used && c.mode == MODE && memcmp(&c.kp, &kp, sizeof(KP)) == 0) { hit = &c; break; }
+    if (hit && hit->exec) return hipGraphLaunch(hit->exec, stream);
+    if (!hit) {   // first sighting: remember it, launch directly
+        ranenv::Cached &c = h->cache[h->cache_next];
+        h->cache_next = (h->cache_next + 1) % (int)(sizeof(h->cache) / sizeof(h->cache[0]));
+        if (c.exec) { (void)hipGraphExecDestroy(c.exec); c.exec = nullptr; }
+        c.used = true; c.mode = MODE; c.seen = 1; memcpy(&c.kp, &kp, sizeof(KP));
+        return enqueue<MODE>(h, kp, stream);
+    }
+    // second sighting: capture
+    hipGraph_t graph = nullptr;
+    const bool dbg = getenv("RANENV_DEBUG") != nullptr;
+    hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        if (dbg) fprintf(stderr, "[ranenv] begin capture: %s\n", hipGetErrorString(e));
+        h->use_graph = false; (void)hipGetLastError(); return enqueue<MODE>(h, kp, stream);
+    }
+    hipError_t e1 = enqueue<MODE>(h, kp, stream);
+    e = hipStreamEndCapture(stream, &graph);
+    if (e1 != hipSuccess || e != hipSuccess || graph == nullptr) {
+        if (dbg) fprintf(stderr, "[ranenv] capture failed: enqueue=%s end=%s\n", hipGetErrorString(e1), hipGetErrorString(e));
+        h->use_graph = false; (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        return enqueue<MODE>(h, kp, stream);
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess || exec == nullptr) {
+        if (dbg) fprintf(stderr, "[ranenv] instantiate: %s\n", hipGetErrorString(e));
+        h->use_graph = false; (void)hipGetLastError(); return enqueue<MODE>(h, kp, stream);
+    }
+    if (dbg) fprintf(stderr, "[ranenv] graph captured for mode %d\n", MODE);
+    hit->exec = exec;
+    return hipGraphLaunch(exec, stream);
 }
 
 }  // namespace
@@ -941,7 +1064,13 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.st.pkt_incoming, B * U); ALLOC(kp.st.pkt_throughputs, B * U); ALLOC(kp.st.pkt_effective_thr, B * U);
     ALLOC(kp.st.dropped_pkts, B * U); ALLOC(kp.st.rb_start, B * U); ALLOC(kp.st.rb_count, B * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
-    ALLOC(kp.st.drift, B * U * 3);
+    {
+        const size_t NSL = (size_t)S * GRP;
+        ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
+        ALLOC(kp.st.slot_q, B * NSL); ALLOC(kp.st.slot_ws, B * NSL); ALLOC(kp.st.slot_sem, B * NSL);
+        ALLOC(kp.st.slot_d0, B * NSL); ALLOC(kp.st.slot_d1, B * NSL); ALLOC(kp.st.slot_d2, B * NSL);
+        ALLOC(kp.st.slot_rbc, B * NSL);
+    }
     ALLOC(h->d_episodes, B);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
@@ -956,6 +1085,28 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
             return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
         }
     }
+    {
+        const char *env_c = getenv("RANENV_CHUNKS");
+        int nc = env_c ? atoi(env_c) : 1;   // measured on MI355X: event-joined chunk streams cost more than they hide
+        if (nc < 1) nc = 1;
+        if (nc > ranenv::MAX_CHUNKS) nc = ranenv::MAX_CHUNKS;
+        if (nc > cfg->batch) nc = cfg->batch;
+        h->n_chunks = nc;
+        const char *env_g = getenv("RANENV_GRAPH");
+        h->use_graph = env_g && atoi(env_g) != 0;   // opt-in: replay needs a capturable (non-null) stream to pay off
+        if (h->use_graph) {
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->main_stream, hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        }
+        if (nc > 1) {
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            for (int c = 0; c < nc; c++) {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->aux[c], hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
+            }
+        }
+    }
     *out = h;
     return RANENV_OK;
 }
@@ -963,6 +1114,17 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
 int ranenv_destroy(ranenv_handle h)
 {
     if (!h) return RANENV_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto &c : h->cache) if (c.exec) (void)hipGraphExecDestroy(c.exec);
+    for (int c = 0; c < ranenv::MAX_CHUNKS; c++) {
+        if (h->aux[c]) (void)hipStreamDestroy(h->aux[c]);
+        if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->main_stream) (void)hipStreamDestroy(h->main_stream);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
     return RANENV_OK;
@@ -1011,6 +1173,18 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
         if (t->ue_slice[i] < -1 || t->ue_slice[i] >= S) return fail(h, RANENV_E_INVALID, "ue_slice %d outside [-1,%d)", t->ue_slice[i], S);
         if (t->ue_pos[i] < 0 || t->ue_pos[i] >= Us) return fail(h, RANENV_E_INVALID, "ue_pos %d outside [0,%d)", t->ue_pos[i], Us);
     }
+    // slot tables: slot = slice*16 + position -> UE id and that UE's buffer parameters
+    const size_t NSL = (size_t)S * GRP;
+    std::vector<int32_t> sue(n * NSL, -1), smp(n * NSL, 1), spk(n * NSL, 1);
+    for (size_t i = 0; i < n; i++)
+        for (int sl = 0; sl < S; sl++)
+            for (int k = 0; k < t->slice_nues[i * S + sl]; k++) {
+                const int ue = t->slice_ues[(i * S + sl) * Us + k];
+                const size_t o = i * NSL + (size_t)sl * GRP + k;
+                if (t->ue_slice[i * U + ue] != sl || t->ue_pos[i * U + ue] != k)
+                    return fail(h, RANENV_E_INVALID, "scenario %zu: ue_slice/ue_pos disagree with slice_ues", i);
+                sue[o] = ue; smp[o] = t->ue_max_pkts[i * U + ue]; spk[o] = t->ue_pkt_size[i * U + ue];
+            }
     const size_t f = (size_t)first;
     const Tables &d = h->kp.tab;
 #define PUT(dst, src, elems, type) HIP_TRY(h, hipMemcpyAsync((dst), (src), (elems) * sizeof(type), hipMemcpyHostToDevice, stream))
@@ -1024,6 +1198,9 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     PUT(d.ue_pkt_size + f * U, t->ue_pkt_size, n * U, int32_t);
     PUT(d.ue_max_pkts + f * U, t->ue_max_pkts, n * U, int32_t);
     PUT(d.ue_max_age + f * U, t->ue_max_age, n * U, int32_t);
+    PUT(d.slot_ue + f * NSL, sue.data(), n * NSL, int32_t);
+    PUT(d.slot_mp + f * NSL, smp.data(), n * NSL, int32_t);
+    PUT(d.slot_pk + f * NSL, spk.data(), n * NSL, int32_t);
 #undef PUT
     HIP_TRY(h, hipStreamSynchronize(stream));  // staging vectors die at return
     h->have_scenarios = true;
