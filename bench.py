@@ -29,6 +29,18 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def usable_cores() -> int:
+    """Host threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(wl, sample_envs: int, sample_steps: int):
     """Time the CPU oracle (oracle/ranenv_oracle.c, OpenMP over envs) on a bounded sample of the
     same workload: the first `sample_envs` envs of this rank for `sample_steps` TTIs."""
@@ -36,7 +48,7 @@ def cpu_baseline(wl, sample_envs: int, sample_steps: int):
     from oracle import pyoracle
     env = wl.env
     S, U, R, G, Us = env.S, env.U, env.R, env.G, env.Us
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     n = min(sample_envs, env.B)
     cfg = pyoracle.make_cfg(S, U, R, G, Us, bandwidth_hz=env.bandwidth_hz, max_age_cap=env.max_age_cap,
                             max_steps=env.max_steps)
@@ -74,8 +86,8 @@ def main():
                     help="BASELINE.json configs index: 1 = B1024 MARR+RR, 2 = B4096 MAPF+PF (default)")
     ap.add_argument("--traces", type=int, default=200)
     ap.add_argument("--trace-len", type=int, default=200)
-    ap.add_argument("--cpu-envs", type=int, default=512)
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-envs", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,18 +122,19 @@ def main():
     env = wl.env
     env.reset()
     for _ in range(args.warmup):
-        env.step()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        obs, reward, done = env.step()
+    gather_metrics(local_metrics(reward, env.views(), done, 1))   # warm torch's reduction kernels / RCCL
+    ev_start = torch.cuda.Event(enable_timing=True)
+    ev_end = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev_start.record()               # torch's current stream = the stream the kernels are launched on
     for i in range(args.steps):
-        starts[i].record()          # torch's current stream = the stream the kernel is launched on
         obs, reward, done = env.step()
-        ends[i].record()
+    ev_end.record()
     vec = local_metrics(reward, env.views(), done, args.steps)
     gathered = gather_metrics(vec)      # the only collective: metrics, RCCL all_gather
     torch.cuda.synchronize()
@@ -133,13 +146,18 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    step_ms = ev_start.elapsed_time(ev_end) / args.steps      # device time of one TTI (3 kernels)
+    prof = [env.step_profiled() for _ in range(24)][4:]       # per-kernel HIP events, after the timed region
+    kms = {k: float(np.mean([q[k] for q in prof])) for k in ("alloc", "core", "obs")}
     total_env_steps = batch * world * args.steps
     value = total_env_steps / elapsed
 
     if rank == 0:
-        alg_bytes = env.algorithmic_bytes_per_env_step() * batch          # per launch
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        alg_bytes = env.algorithmic_bytes_per_env_step() * batch          # per TTI of the whole batch
+        achieved = alg_bytes / (step_ms * 1e-3) / 1e9                     # whole step: alloc + core + obs
+        # the dominant kernel (core) moves everything except the action/observation term of SURVEY 8(d)
+        core_bytes = (env.algorithmic_bytes_per_env_step() - (env.S * (85 + 8 * env.Us) + 4)) * batch
+        core_gbs = core_bytes / (kms["core"] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -161,8 +179,13 @@ def main():
                        "n_rbs": env.R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ranenv_kernel<MODE_STEP,128>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_env_step": env.algorithmic_bytes_per_env_step()},
+                         "kernel": "one TTI = ranenv_alloc_kernel + ranenv_core_kernel<STEP,128> + ranenv_obs_kernel<STEP>",
+                         "kernel_ms": step_ms,
+                         "algorithmic_bytes_per_env_step": env.algorithmic_bytes_per_env_step(),
+                         "dominant_kernel": {"name": "ranenv_core_kernel<STEP,128>", "ms": kms["core"],
+                                             "algorithmic_bytes": core_bytes, "achieved": core_gbs,
+                                             "frac": core_gbs / HBM_PEAK_GBS},
+                         "other_kernels_ms": {"alloc": kms["alloc"], "obs": kms["obs"]}},
             "metrics": summarize(gathered.cpu()),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -195,6 +195,10 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
 
+/* Diagnostic: one TTI (device policy, bound pools, no observation outputs) with HIP events
+ * around each kernel; blocks until it finished.  ms3 = {alloc, core, obs} durations in ms. */
+int ranenv_step_profiled(ranenv_handle h, float *ms3, void *stream);
+
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */

@@ -19,7 +19,8 @@ F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT = 0x1, 0x2
 EXPORTS = (
     "ranenv_last_error", "ranenv_abi_version", "ranenv_create", "ranenv_destroy",
     "ranenv_load_scenarios", "ranenv_bind_se_pool", "ranenv_bind_traffic_pool", "ranenv_set_episodes",
-    "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_get_views",
+    "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_step_profiled",
+    "ranenv_get_views",
     "ranenv_launch_info",
 )
 
@@ -102,6 +103,7 @@ def load() -> C.CDLL:
     lib.ranenv_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ranenv_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.ranenv_step_dense.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+    lib.ranenv_step_profiled.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
     lib.ranenv_get_views.argtypes = [C.c_void_p, C.POINTER(Views)]
     lib.ranenv_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     if lib.ranenv_abi_version() != ABI_VERSION:

@@ -254,6 +254,12 @@ class BatchedRanEnv:
             "buffer_latencies": lat,
         }
 
+    def step_profiled(self):
+        """Diagnostic: one TTI with HIP events around each kernel -> {'alloc','core','obs'} in ms."""
+        ms = (C.c_float * 3)()
+        self._check(self._lib.ranenv_step_profiled(self._h, ms, self._stream()), "ranenv_step_profiled")
+        return {"alloc": ms[0], "core": ms[1], "obs": ms[2]}
+
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self._lib.ranenv_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)), "ranenv_launch_info")

@@ -862,6 +862,8 @@ struct ranenv {
     Cached cache[6];
     int cache_next = 0;
     bool use_graph = true;
+    bool prof_on = false;               // ranenv_step_profiled: events around each kernel
+    hipEvent_t prof_ev[4] = {};
     std::string err;
 };
 
@@ -919,10 +921,15 @@ void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
 {
     kp.e0 = e0;
     const dim3 sblock((unsigned)(((kp.S * GRP) + WAVE - 1) / WAVE * WAVE));   // one thread per slot
+    hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;       // diagnostic per-kernel timing
+    if (ev) (void)hipEventRecord(ev[0], stream);
     if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
+    if (ev) (void)hipEventRecord(ev[1], stream);
     launch_core<MODE>(h, kp, n_env, stream);
+    if (ev) (void)hipEventRecord(ev[2], stream);
     if (MODE == MODE_RESET) hipLaunchKernelGGL((ranenv_obs_kernel<MODE_RESET>), dim3(n_env), sblock, 0, stream, kp);
     else hipLaunchKernelGGL((ranenv_obs_kernel<MODE_STEP>), dim3(n_env), sblock, 0, stream, kp);
+    if (ev) (void)hipEventRecord(ev[3], stream);
 }
 
 // Fork the caller's stream into the chunk streams and join them back.
@@ -1122,6 +1129,7 @@ int ranenv_destroy(ranenv_handle h)
         if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
     if (h->main_stream) (void)hipStreamDestroy(h->main_stream);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
@@ -1313,6 +1321,28 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     kp.dense = dense; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     hipError_t e = launch<MODE_DENSE>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "dense step launch: %s", hipGetErrorString(e));
+    return RANENV_OK;
+}
+
+int ranenv_step_profiled(ranenv_handle h, float *ms3, void *stream_)
+{
+    if (!h || !ms3) return fail(h, RANENV_E_INVALID, "null argument");
+    int rc = check_ready(h, nullptr, nullptr, true);
+    if (rc != RANENV_OK) return rc;
+    if (!h->kp.se_pool || !h->kp.trf_pool || h->kp.policy == RANENV_POLICY_EXTERNAL)
+        return fail(h, RANENV_E_STATE, "ranenv_step_profiled needs bound pools and a device policy");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (auto &e : h->prof_ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
+    hipStream_t stream = (hipStream_t)stream_;
+    KP kp = h->kp;
+    kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
+    kp.dense = nullptr; kp.obs_inter = nullptr; kp.obs_intra = nullptr; kp.reward = nullptr; kp.done = nullptr;
+    h->prof_on = true;
+    launch_chunk<MODE_STEP>(h, kp, 0, kp.B, stream);
+    h->prof_on = false;
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventSynchronize(h->prof_ev[3]));
+    for (int k = 0; k < 3; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
     return RANENV_OK;
 }
 
