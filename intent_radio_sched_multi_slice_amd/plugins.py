@@ -1,0 +1,250 @@
+"""Plugin surfaces of the env core, mirrored from the reference's call sites.
+
+The reference's plugins subclass four base classes of ``sixg_radio_mgmt`` (an un-vendored git
+submodule).  Their constructor orders and ``step`` signatures are pinned by the subclasses in the
+reference tree:
+
+    Association(ues, max_number_ues, max_number_basestations, max_number_slices, rng, root_path)
+        associations/mult_slice.py:21-28        step(...)  :350-358
+    Traffic(max_number_ues, rng, root_path)     traffics/mult_slice.py:13   step(...) :15-21
+    Channel(max_number_ues, max_number_basestations, num_available_rbs, rng, root_path, scenario_name)
+        channels/quadriga.py:19-26              step(...)  :38-44
+    Mobility(max_number_ues, rng, root_path)    mobilities/simple.py:13     step(...) :15
+    Agent(env, max_number_ues, max_number_slices, max_number_basestations, num_available_rbs, seed)
+        agents/ib_sched.py:39-45
+
+so a plugin written against the reference attaches to ``MARLCommEnv`` (comm_env.py) unchanged.
+The concrete plugins below restate the reference's own ones; they are host-side numpy, called
+once per TTI by the B=1 facade only (the batched path replays pools from HBM instead).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .scenario import SLICE_TEMPLATES, generate_reference_scenario, slice_template_dict
+
+
+# --------------------------------------------------------------------------------------------
+# base classes (attribute holders, like the reference's)
+# --------------------------------------------------------------------------------------------
+class _Buffer:
+    """What the reference reads off ``ues.buffers[i]`` (gen_assoc_mult_slice.py:218-224)."""
+
+    def __init__(self, max_packets_buffer: int, max_packets_age: int):
+        self.max_packets_buffer = int(max_packets_buffer)
+        self.max_packets_age = int(max_packets_age)
+
+
+class UEs:
+    """Per-UE buffer parameters; the queues themselves live on the GPU.
+
+    Constructor order from gen_assoc_mult_slice.py:92-97; ``update_ues`` argument order from
+    associations/mult_slice.py:483-488; attributes ``max_buffer_pkts`` / ``pkt_sizes`` read by
+    agents/common.py:581-582,591.
+    """
+
+    def __init__(self, max_number_ues, max_buffer_latencies, max_buffer_pkts, pkt_sizes):
+        self.max_number_ues = int(max_number_ues)
+        self.max_buffer_latencies = np.array(max_buffer_latencies, dtype=np.int64).copy()
+        self.max_buffer_pkts = np.array(max_buffer_pkts, dtype=np.int64).copy()
+        self.pkt_sizes = np.array(pkt_sizes, dtype=np.int64).copy()
+        self.version = 0   # bumped on every update: the env reloads the device tables
+        self._rebuild()
+
+    def _rebuild(self):
+        self.buffers = [_Buffer(self.max_buffer_pkts[i], self.max_buffer_latencies[i])
+                        for i in range(self.max_number_ues)]
+
+    def update_ues(self, ue_indexes, max_buffer_latencies, max_buffer_pkts, pkt_sizes):
+        self.max_buffer_latencies[ue_indexes] = max_buffer_latencies
+        self.max_buffer_pkts[ue_indexes] = max_buffer_pkts
+        self.pkt_sizes[ue_indexes] = pkt_sizes
+        self.version += 1
+        self._rebuild()
+
+
+class Agent:
+    def __init__(self, env, max_number_ues, max_number_slices, max_number_basestations, num_available_rbs, seed=0):
+        self.env = env
+        self.max_number_ues = max_number_ues
+        self.max_number_slices = max_number_slices
+        self.max_number_basestations = max_number_basestations
+        self.num_available_rbs = num_available_rbs
+        self.seed = seed
+
+
+class Association:
+    def __init__(self, ues, max_number_ues, max_number_basestations, max_number_slices,
+                 rng=None, root_path: str = ""):
+        self.ues = ues
+        self.max_number_ues = max_number_ues
+        self.max_number_basestations = max_number_basestations
+        self.max_number_slices = max_number_slices
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.root_path = root_path
+
+    def step(self, basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req,
+             step_number, episode_number):
+        raise NotImplementedError
+
+
+class Traffic:
+    def __init__(self, max_number_ues, rng=None, root_path: str = ""):
+        self.max_number_ues = max_number_ues
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.root_path = root_path
+
+    def step(self, slice_ue_assoc, slice_req, step_number, episode_number):
+        raise NotImplementedError
+
+
+class Channel:
+    def __init__(self, max_number_ues, max_number_basestations, num_available_rbs, rng=None,
+                 root_path: str = "", scenario_name: str = ""):
+        self.max_number_ues = max_number_ues
+        self.max_number_basestations = max_number_basestations
+        self.num_available_rbs = num_available_rbs
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.root_path = root_path
+        self.scenario_name = scenario_name
+
+    def step(self, step_number, episode_number, mobilities, sched_decision=None):
+        raise NotImplementedError
+
+
+class Mobility:
+    def __init__(self, max_number_ues, rng=None, root_path: str = ""):
+        self.max_number_ues = max_number_ues
+        self.rng = rng if rng is not None else np.random.default_rng()
+        self.root_path = root_path
+
+    def step(self, step_number, episode_number):
+        raise NotImplementedError
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's own plugins, restated
+# --------------------------------------------------------------------------------------------
+class SimpleMobility(Mobility):
+    """mobilities/simple.py:15-16"""
+
+    def step(self, step_number, episode_number):
+        return np.ones((self.max_number_ues, 2))
+
+
+class SimpleTraffic(Traffic):
+    """traffics/simple.py:15-22: constant 4 bits per UE."""
+
+    def step(self, slice_ue_assoc, slice_req, step_number, episode_number):
+        return np.ones(self.max_number_ues) * 4
+
+
+class MultSliceTraffic(Traffic):
+    """traffics/mult_slice.py:15-34: Poisson(slice Mbps) * 1e6 bits for the UEs of each slice,
+    slices in dict order, one generator call per slice."""
+
+    def step(self, slice_ue_assoc, slice_req, step_number, episode_number):
+        traffic_per_ue = np.zeros(self.max_number_ues)
+        for name, req in slice_req.items():
+            if req != {}:
+                s = int(name.split("_")[1])
+                idx_ues = (slice_ue_assoc[s, :] == 1).nonzero()[0]
+                traffic_per_ue[idx_ues] = self.rng.poisson(req["ues"]["traffic"], len(idx_ues)) * 1e6
+        return traffic_per_ue
+
+
+class FixedSE(Channel):
+    """channels/fixed_se.py:26,35-41: SE = 2.0 everywhere."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.fixed_se = 2.0
+
+    def step(self, step_number, episode_number, mobilities, sched_decision=None):
+        return np.array([self.fixed_se * np.ones((self.max_number_ues, self.num_available_rbs[i]))
+                         for i in range(self.max_number_basestations)])
+
+
+class MimicQuadriga(Channel):
+    """channels/mimic_quadriga.py:30-58: per-episode UE means |N(10, 7.5)|, per-TTI |N(mean, 1.5)|."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.current_episode_number = -1
+        self.ues_mean_se = np.array([])
+        self.default_std = 1.5
+
+    def step(self, step_number, episode_number, mobilities, sched_decision=None):
+        if episode_number != self.current_episode_number:
+            self.current_episode_number = episode_number
+            self.ues_mean_se = np.abs(self.rng.normal(10, 7.5, size=(self.max_number_ues,)))
+        se = np.ones((self.max_number_basestations, self.max_number_ues, self.num_available_rbs[0]))
+        for ue_idx, ue_mean in enumerate(self.ues_mean_se):
+            se[0, ue_idx, :] = np.abs(self.rng.normal(ue_mean, self.default_std, size=(self.num_available_rbs[0],)))
+        return se
+
+
+class PoolChannel(Channel):
+    """Replay of a precomputed SE array [episodes][steps][U][R] (what channels/quadriga.py:38-76 does
+    from target_cell_power.mat after log2(1 + P*g/N); the HDF5 reader itself is out of scope)."""
+
+    def __init__(self, *a, pool: Optional[np.ndarray] = None, **k):
+        super().__init__(*a, **k)
+        self.pool = pool
+
+    def step(self, step_number, episode_number, mobilities, sched_decision=None):
+        ep = self.pool[episode_number % self.pool.shape[0]]
+        return ep[step_number % ep.shape[0]][None, :, :]
+
+
+def quadriga_se_from_power(target_cell_power: np.ndarray, n_rbs: int, transmission_power: float = 100.0,
+                           thermal_noise_power: float = 10e-14) -> np.ndarray:
+    """channels/quadriga.py:56-69: log2(1 + (P / n_rbs) * g / (0 + noise))."""
+    return np.log2(1 + np.divide((transmission_power / n_rbs) * target_cell_power,
+                                 np.zeros_like(target_cell_power) + thermal_noise_power))
+
+
+class SimpleAssociation(Association):
+    """associations/simple.py:27-41: pass-through."""
+
+    def step(self, basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req,
+             step_number, episode_number):
+        return basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req
+
+
+class MultSliceAssociation(Association):
+    """associations/mult_slice.py generator mode (:359-423) plus update_ues (:468-488).
+
+    The replay mode of the reference reads ``associations/data/mult_slice/ep_N.npz`` (pickled
+    dicts, absent from the snapshot); here a scenario is generated per episode from the same
+    generator law, consuming the shared rng in the reference's call order.
+    """
+
+    def __init__(self, ues, max_number_ues, max_number_basestations, max_number_slices, rng=None,
+                 root_path: str = ".", generator_mode: bool = True, scenario_name: str = "mult_slice"):
+        super().__init__(ues, max_number_ues, max_number_basestations, max_number_slices, rng, root_path)
+        self.min_number_slices = 3
+        self.generator_mode = generator_mode
+        self.slice_types = [t[0] for t in SLICE_TEMPLATES]
+        self.slice_type_model = {t[0]: slice_template_dict(i) for i, t in enumerate(SLICE_TEMPLATES)}
+        self.slices_to_use = np.array([])
+        self.current_episode = -1
+
+    def step(self, basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req,
+             step_number, episode_number):
+        if step_number == 0:
+            bua, bsa, sua, req, slices = generate_reference_scenario(
+                self.rng, self.max_number_slices, self.max_number_ues, self.min_number_slices)
+            self.slices_to_use = slices
+            self.update_ues(sua, slices, req)
+            return bua, bsa, sua, req
+        return basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req
+
+    def update_ues(self, slice_ue_assoc, slices_to_use, slice_req):
+        for s in slices_to_use:
+            ues = (slice_ue_assoc[s] == 1).nonzero()[0]
+            u = slice_req[f"slice_{s}"]["ues"]
+            self.ues.update_ues(ues, np.repeat(u["buffer_latency"], len(ues)),
+                                np.repeat(u["buffer_size"], len(ues)), np.repeat(u["message_size"], len(ues)))

@@ -1,0 +1,170 @@
+"""CPU-only checks of the host layer: scenario tables, bundled plugins against the golden vectors
+captured from the reference, the C-ABI library's exports, and the multi-process metrics gather."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+from intent_radio_sched_multi_slice_amd import plugins, scenario
+from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables
+from tests.common import load_golden, tables_from
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generator_reproduces_reference_scenarios():
+    """generate_reference_scenario consumes the rng like MultSliceAssociation's generator mode
+    (associations/mult_slice.py:359-423): seed 10, episodes 0..9 (gen_assoc_mult_slice.py:14)."""
+    fx = load_golden("assoc_traffic")
+    rng = np.random.default_rng(10)
+    for ep in range(10):
+        bua, bsa, sua, req, slices = scenario.generate_reference_scenario(rng, 5, 25)
+        assert np.array_equal(bsa, fx["assoc_bsa"][ep])
+        assert np.array_equal(sua, fx["assoc_sua"][ep])
+        types = [scenario.SLICE_TYPE_NAMES.index(req[f"slice_{s}"]["name"]) if req[f"slice_{s}"] else -1 for s in range(5)]
+        assert types == list(fx["assoc_types"][ep])
+        assert np.sum(sua.sum(axis=0) > 1) == 0                       # gen_assoc_mult_slice.py:194-195
+        assert sua.sum() == bua.sum()                                 # :197-200
+
+
+def test_tables_from_reference_objects_match_golden_tables():
+    fx = load_golden("assoc_traffic")
+    gold = tables_from(fx, "assoc_tab_")
+    rng = np.random.default_rng(10)
+    t = ScenarioTables.empty(10, 5, 25, 5)
+    for ep in range(10):
+        bua, bsa, sua, req, _ = scenario.generate_reference_scenario(rng, 5, 25)
+        t.set_from_reference(ep, bsa, sua, req, True)
+    for name, arr in gold.arrays().items():
+        got = getattr(t, name)
+        if name in ("ue_pkt_size", "ue_max_pkts", "ue_max_age"):
+            mask = gold.ue_slice >= 0                                  # idle UEs: defaults differ by design
+            assert np.array_equal(got[mask], arr[mask]), name
+        else:
+            assert np.array_equal(got, arr), name
+
+
+def test_tables_roundtrip_and_validation():
+    t = scenario.generate_scaled_scenarios(5, seed=3)
+    for i in range(t.n_scenarios):
+        bua, bsa, sua, req = t.to_reference(i)
+        t2 = ScenarioTables.empty(1, t.n_slices, t.n_ues, t.max_ues_slice)
+        t2.set_from_reference(0, bsa, sua, req, True)
+        for name in ("slice_active", "slice_nues", "slice_ues", "param_metric", "param_op", "param_value",
+                     "sorted_slices", "ue_slice", "ue_pos", "ue_pkt_size", "ue_max_pkts", "ue_max_age"):
+            assert np.array_equal(getattr(t2, name)[0], getattr(t, name)[i]), name
+        assert 6 <= int(t.slice_active[i].sum()) <= 10
+        n = t.slice_nues[i][t.slice_active[i] == 1]
+        assert n.min() >= 4 and n.max() <= 10
+    t.validate(400, 135, 100e6)
+    with pytest.raises(ValueError):
+        t.validate(100, 135, 100e6)            # uav_app_case_1 needs 400 TTIs
+    bad = np.zeros((10, 100)); bad[0, 3] = bad[1, 3] = 1
+    with pytest.raises(ValueError):
+        t.set_from_reference(0, np.ones((1, 10)), bad, {f"slice_{s}": {} for s in range(10)})
+
+
+def test_mult_slice_traffic_draw_order_matches_reference():
+    """traffics/mult_slice.py:24-32 for seeds 10 and 15 (simu.py:203-204)."""
+    fx = load_golden("assoc_traffic")
+    tabs = tables_from(fx, "assoc_tab_")
+    bua, bsa, sua, req = tabs.to_reference(0)
+    for seed in (10, 15):
+        tr = plugins.MultSliceTraffic(25, np.random.default_rng(seed))
+        got = np.array([tr.step(sua, req, t, 0) for t in range(20)])
+        assert np.array_equal(got, fx[f"traffic_seed{seed}"])
+
+
+def test_simple_plugins():
+    assert np.array_equal(plugins.SimpleTraffic(4, None).step(None, None, 0, 0), np.full(4, 4.0))
+    se = plugins.FixedSE(4, 1, np.array([25]), None).step(0, 0, None)
+    assert se.shape == (1, 4, 25) and np.all(se == 2.0)
+    assert plugins.SimpleMobility(4, None).step(0, 0).shape == (4, 2)
+    ues = plugins.UEs(5, np.repeat(100, 5), np.repeat(1024, 5), np.repeat(100, 5))
+    ues.update_ues(np.array([1, 3]), np.array([20, 20]), np.array([10, 10]), np.array([8, 8]))
+    assert ues.buffers[1].max_packets_age == 20 and ues.max_buffer_pkts[3] == 10 and ues.pkt_sizes[0] == 100
+    se_q = plugins.quadriga_se_from_power(np.array([[1e-12]]), 135)
+    assert np.isclose(se_q[0, 0], np.log2(1 + (100 / 135) * 1e-12 / 1e-13))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The HIP library must load on a CPU-only host and export what include/ranenv.h declares."""
+    from intent_radio_sched_multi_slice_amd import _lib
+    from intent_radio_sched_multi_slice_amd.csrc import build
+    build.build()
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "ranenv.h")).read()
+    declared = set(re.findall(r"\b(ranenv_[a-z_]+)\s*\(", header))
+    declared -= {"ranenv_config", "ranenv_handle"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.ranenv_abi_version() == _lib.ABI_VERSION
+    assert ctypes.sizeof(_lib.Episode) == 40 and ctypes.sizeof(_lib.Config) == 96
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "intent_radio_sched_multi_slice_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "pyoracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+                assert "libranenv_oracle" not in text, f
+
+
+def test_shard_range_partitions_the_batch():
+    from intent_radio_sched_multi_slice_amd.dist import shard_range
+    for total in (1, 7, 4096, 32768, 32771):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _gather_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from intent_radio_sched_multi_slice_amd.dist import gather_metrics, local_metrics, shard_range, summarize
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(10, rank, world)
+    b = hi - lo
+    reward = torch.full((b, 3), -0.5 if rank == 0 else 0.25, dtype=torch.float64)
+    views = {k: torch.full((b, 4), rank + 1, dtype=torch.int32) for k in
+             ("pkt_effective_thr", "dropped_pkts", "pkt_incoming", "queue_pkts")}
+    g = gather_metrics(local_metrics(reward, views, torch.zeros(b, dtype=torch.uint8), 5))
+    out.put((rank, summarize(g), tuple(g.shape)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_metrics_gather_world_size_2_gloo():
+    """The only collective of the build: all ranks end with every rank's
+    accumulator vector; on GPUs the same call runs over RCCL."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, summ, shape in res:
+        assert shape == (2, 8)
+        assert summ["env_steps"] == 10 * 5
+        assert summ["violations"] == 5                       # rank 0's five envs have negative reward
+        assert summ["pkts_sent"] == 5 * 4 * 1 + 5 * 4 * 2
+        assert np.isclose(summ["reward_inter_sum"], 5 * -0.5 + 5 * 0.25)
