@@ -32,6 +32,9 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls on one
  *     handle must be serialised by the caller; work is enqueued, not synchronised.
  *   - there is no CPU fallback: if no gfx950 device/kernel image is usable the calls fail.
+ *   - sizes supported by this build: S <= 16, max_ues_slice <= 16, U <= 1024, R <= 512,
+ *     hist_depth <= 64; packet counts must stay below 2^31 (checked when scenarios are loaded).
+ *   - SE tiles are RB-major: element (rb r, ue u) of a tile at offset r*U + u.
  */
 #ifndef RANENV_H
 #define RANENV_H
@@ -157,8 +160,8 @@ int ranenv_destroy(ranenv_handle h);
 int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count,
                           const ranenv_scenario_tables *host_tables, void *stream);
 
-/* SE pool: float32 tiles of U*R values (row u = UE u, RB-contiguous), tile i at
- * dev + i*tile_stride floats; tile_stride >= U*R and a multiple of 4. */
+/* SE pool: float32 tiles of R*U values, RB-major (value of RB r, UE u at r*U + u), tile i at
+ * dev + i*tile_stride floats; tile_stride >= U*R. */
 int ranenv_bind_se_pool(ranenv_handle h, const float *dev_pool, int64_t n_tiles, int64_t tile_stride);
 /* Traffic pool: int32 offered bits, row i = [U] at dev + i*U. */
 int ranenv_bind_traffic_pool(ranenv_handle h, const int32_t *dev_pool, int64_t n_rows);
@@ -181,7 +184,7 @@ int ranenv_reset(ranenv_handle h, const uint8_t *dev_env_mask, const float *dev_
  *   dev_inter_scores [B][S] double  action["player_0"]; NULL = device policy
  *   dev_intra_choice [B][S] uint8   action["player_{s+1}"]; NULL = fixed_intra
  *   dev_traffic_bits [B][U] double  traffic.step() output; NULL = traffic pool
- *   dev_se_tiles     [B][U*R] float channel.step() output; NULL = SE pool
+ *   dev_se_tiles     [B][R][U] float channel.step() output, RB-major; NULL = SE pool
  *   outputs: obs (float32), reward (double, [0] = player_0), done (uint8: step == max_steps) */
 int ranenv_step(ranenv_handle h, const double *dev_inter_scores, const uint8_t *dev_intra_choice,
                 const double *dev_traffic_bits, const float *dev_se_tiles,
