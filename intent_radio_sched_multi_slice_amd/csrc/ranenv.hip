@@ -70,6 +70,7 @@ struct State {
     int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
     int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
+    double *se_part;            // [B][U] sum of SE over the UE's allocated RBs, stream -> ue
     // slot-ordered records, slot = slice*16 + position: written by core (alloc for rbc), read
     // coalesced by alloc and obs                                         [B][S*16]
     int32_t *slot_q; int64_t *slot_ws; double *slot_sem; double *slot_d0, *slot_d1, *slot_d2; int32_t *slot_rbc;
@@ -280,10 +281,102 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     full = lf + rf; part = lg + rg;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two lanes per SE row: lane h of a UE's pair owns numpy's accumulators 4h..4h+3, i.e. rows
+// 4h..4h+3 of every 8-row group.  The leaf result is ((r0+r1)+(r2+r3)) from lane 0 plus
+// ((r4+r5)+(r6+r7)) from lane 1 -- exactly numpy's combination tree, one cross-lane add -- so the sums
+// are bit-identical to the one-lane form while each lane's dependent chain, accumulator registers
+// and loads per group are halved; the freed registers hold a 6-group-deep load queue.
+// ---------------------------------------------------------------------------------------------
+struct SeStream2 {
+    float q[6][4];
+    float tl[7];                   // the row's tail (R mod 8 elements), same for both lanes
+    __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
+    int voff, voff_u, row_bytes;
+
+    DEVFN void load(float (&dst)[4], int r0)
+    {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+            dst[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (r0 + a) * row_bytes, 0));
+    }
+    DEVFN void init(const float *tile, int U, int u, int h, int R)
+    {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
+        voff_u = u * 4; voff = (4 * h * U + u) * 4; row_bytes = U * 4;
+        const int G = R >> 3, tail = R & 7;
+#pragma unroll
+        for (int d = 0; d < 6; d++) if (d < G) load(q[d], d * 8);
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            tl[j] = j < tail ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_u, (G * 8 + j) * row_bytes, 0)) : 0.0f;
+    }
+};
+
+// in(r) is evaluated for the lane's own rows; both lanes of a pair return the same sums.
+template <typename InFn>
+DEVFN void row_sums2(SeStream2 &st, int R, int h, InFn in, double &full, double &part)
+{
+    const RowPlan pl = make_row_plan(R);
+    const int tail = R & 7, G = R >> 3;
+    double f[4] = {0.0, 0.0, 0.0, 0.0}, g[4] = {0.0, 0.0, 0.0, 0.0};
+    double fr = 0.0, gr = 0.0, lf = 0.0, lg = 0.0, rf = 0.0, rg = 0.0;
+    int leaf = 0, left_in_leaf = pl.len0 >> 3;            // wave-uniform cursor
+    auto fold = [&](int k) {
+        const bool left = pl.lsplit ? (k < 2) : (k < 1);
+        const bool first = pl.lsplit ? (k == 0 || k == 2) : (k <= 1);
+        if (left) { if (first) { lf = fr; lg = gr; } else { lf = lf + fr; lg = lg + gr; } }
+        else      { if (first) { rf = fr; rg = gr; } else { rf = rf + fr; rg = rg + gr; } }
+    };
+    auto consume = [&](const float (&x)[4], int r0) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const float xs = in(r0 + 4 * h + a) ? x[a] : 0.0f;
+            f[a] += (double)x[a];
+            g[a] += (double)xs;
+        }
+        if (--left_in_leaf == 0) {
+            const double tf = (f[0] + f[1]) + (f[2] + f[3]), tg = (g[0] + g[1]) + (g[2] + g[3]);
+            const double of = __shfl_xor(tf, 1), og = __shfl_xor(tg, 1);
+            fr = h == 0 ? tf + of : of + tf;          // (r0..r3) + (r4..r7), the same bits in both lanes
+            gr = h == 0 ? tg + og : og + tg;
+#pragma unroll
+            for (int a = 0; a < 4; a++) { f[a] = 0.0; g[a] = 0.0; }
+            if (!(leaf == pl.n_leaves - 1 && tail > 0)) fold(leaf);
+            leaf += 1;
+            left_in_leaf = ((leaf == 1) * pl.len1 + (leaf == 2) * pl.len2 + (leaf == 3) * pl.len3) >> 3;
+        }
+    };
+#pragma unroll 1
+    for (int gi = 0; gi < G; gi += 6) {
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            if (gi + d < G) {
+                consume(st.q[d], (gi + d) * 8);
+                if (gi + d + 6 < G) st.load(st.q[d], (gi + d + 6) * 8);
+            }
+        }
+    }
+    if (tail > 0) {
+        if (G == 0) { fr = 0.0; gr = 0.0; }                  // n < 8: numpy's plain loop from 0.0
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            if (j < tail) {
+                const float xs = in(G * 8 + j) ? st.tl[j] : 0.0f;
+                fr += (double)st.tl[j];
+                gr += (double)xs;
+            }
+        }
+        fold(pl.n_leaves - 1);
+    }
+    if (pl.n_leaves == 1) { full = lf; part = lg; return; }
+    full = lf + rf; part = lg + rg;
+}
+
 #define RANENV_STAMP(k) do { } while (0)
 
 // =============================================================================================
-// Kernel 1/3  alloc: one workgroup = one env, thread = (slice s = tid / 16, UE slot = tid % 16).
+// Kernel 1/4  alloc: one workgroup = one env, thread = (slice s = tid / 16, UE slot = tid % 16).
 //   Policy  MARR agents/marr.py:40-47, MAPF agents/mapf.py:41-111
 //   Inter   IBSched.action_format agents/ib_sched.py:240-269, scores_to_rbs / round_int_equal_sum
 //           agents/common.py:442-505          (threads 0..15, one per slice)
@@ -479,21 +572,18 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 }
 
 // =============================================================================================
-// Kernel 2/3  core: lane = UE.  SE row stream -> capacity -> UEs.step -> intent drift.
-//   No LDS, no barriers: everything a UE needs is its own row, its own state and its slice's
-//   table row.  UEs.step / Buffer: oracle/ranenv_oracle.c (sixg_radio_mgmt is un-vendored);
-//   intent_drift_calc agents/common.py:68-340.
+// Kernel 2/4  stream: two lanes per UE reduce that UE's SE row (mean over all RBs, sum over its
+//   allocated RBs).  Nothing else: no LDS, no barriers, ~70 VGPRs, every resident wave streams.
 // =============================================================================================
-template <int MODE, int NT>
-__global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
+constexpr int STREAM_NT_MAX = 1024;
+
+template <int MODE>
+__global__ void __launch_bounds__(256) ranenv_stream_kernel(const KP p)
 {
     const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
     if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
-    const int S = p.S, U = p.U, R = p.R, D = p.D;
-
-    // Everything read here is the same for the whole workgroup: pin it to scalar registers so the
-    // SE loads use the saddr + 32-bit lane-offset form instead of per-lane 64-bit addresses.
+    const int U = p.U, R = p.R;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto uni64 = [](long long v) {
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -501,39 +591,76 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
     };
     ranenv_episode ep = p.episodes[e];
-    ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
-    ep.se_base = uni64(ep.se_base); ep.trf_base = uni64(ep.trf_base);
+    ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.se_base = uni64(ep.se_base);
     const int sc = ep.scenario;
-    const int t = (MODE == MODE_RESET) ? 0 : uni(p.st.step_no[e]);
-    int hlen = uni(p.st.hist_len[e]);
-    const int npush = uni(p.st.n_push[e]);                    // kept in [0, D)
     const int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[e]);
-    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[e]);
-    const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
-    if (clear_hist) hlen = 0;
-    const int hlen_new = hlen < D ? hlen + 1 : D;
-
     const float *tile;
     if (p.se_tiles != nullptr) tile = p.se_tiles + (size_t)e * U * R;
     else tile = p.se_pool + (size_t)(ep.se_base + (long long)se_pos) * (size_t)p.se_stride;
 
-    const bool act = tid < U;
-    const int u = act ? tid : U - 1;          // idle lanes shadow the last UE (loads stay in bounds)
-    SeStream se;
-    se.init(tile, U, u, R);                   // SE loads are in flight from here on
+    const int ur = tid >> 1, h = tid & 1;
+    const bool act = ur < U;
+    const int u = act ? ur : U - 1;           // idle lanes shadow the last UE (loads stay in bounds)
+    SeStream2 se;
+    se.init(tile, U, u, h, R);                // 24 + tail loads in flight from here on
+    const size_t su = (size_t)e * U + u;
+    double se_full = 0.0, se_part = 0.0;
+    int rb_start = 0, rb_count = 0;
+    if (MODE == MODE_STEP) {
+        if (p.tab.ue_slice[(size_t)sc * U + u] >= 0) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
+        const unsigned ust = (unsigned)rb_start, ucn = (unsigned)rb_count;
+        row_sums2(se, R, h, [=](int r) { return ((unsigned)r - ust) < ucn; }, se_full, se_part);
+    } else if (MODE == MODE_DENSE) {
+        const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
+        row_sums2(se, R, h, [=](int r) { return mrow[r] != 0; }, se_full, se_part);
+        bool seen = false;
+        for (int r = 0; r < R; r++) {
+            if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
+        }
+    } else {
+        row_sums2(se, R, h, [](int) { return false; }, se_full, se_part);
+    }
+    if (act && h == 0) {
+        p.st.se_mean[su] = se_full / (double)R;
+        p.st.se_part[su] = se_part;
+        if (MODE != MODE_STEP || rb_count == 0) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
+    }
+}
 
-    // ---- everything else this UE needs, issued before the row loop so it lands underneath it ----
+// =============================================================================================
+// Kernel 3/4  ue: lane = (env, UE), flat.  Capacity -> UEs.step -> 10-TTI window -> intent drift.
+//   UEs.step / Buffer: oracle/ranenv_oracle.c (sixg_radio_mgmt is un-vendored);
+//   intent_drift_calc agents/common.py:68-340.
+// =============================================================================================
+template <int MODE>
+__global__ void __launch_bounds__(256) ranenv_ue_kernel(const KP p, const int n_env)
+{
+    const int S = p.S, U = p.U, D = p.D;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n_env * U) return;
+    const int e = p.e0 + (int)(idx / U), u = (int)(idx % U);
+    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;
+    const ranenv_episode ep = p.episodes[e];
+    const int sc = ep.scenario;
+    const int t = (MODE == MODE_RESET) ? 0 : p.st.step_no[e];
+    int hlen = p.st.hist_len[e];
+    const int npush = p.st.n_push[e];                         // kept in [0, D)
+    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : p.st.trf_pos[e];
+    const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
+    if (clear_hist) hlen = 0;
+    const int hlen_new = hlen < D ? hlen + 1 : D;
+
     const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
     const int slc = p.tab.ue_slice[tu], ue_pos = p.tab.ue_pos[tu];
     const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
-    int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
+    int total = 0, front = 0, front_rem = 0, fifo = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     if (MODE != MODE_RESET) {
         total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
         front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
     }
     if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
-    if (MODE == MODE_STEP && slc >= 0) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
+    const int rb_count = p.st.rb_count[su];
     int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
     int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
@@ -541,25 +668,8 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
     double traffic = 0.0;
     if (MODE != MODE_RESET)
         traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
+    const double se_mean_new = p.st.se_mean[su], se_part = p.st.se_part[su];
     const double occ_prev = (double)total / (double)max_pkts;
-
-    // ---- this UE's SE row: mean over all RBs and sum over its allocated RBs ----------------------
-    double se_full = 0.0, se_part = 0.0;
-    if (MODE == MODE_STEP) {
-        const unsigned ust = (unsigned)rb_start, ucn = (unsigned)rb_count;
-        row_sums(se, R, [=](int r) { return ((unsigned)r - ust) < ucn; }, se_full, se_part);
-    } else if (MODE == MODE_DENSE) {
-        const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-        row_sums(se, R, [=](int r) { return mrow[r] != 0; }, se_full, se_part);
-        bool seen = false;
-        for (int r = 0; r < R; r++) {
-            if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
-        }
-    } else {
-        row_sums(se, R, [](int) { return false; }, se_full, se_part);
-    }
-    if (!act) return;
-    const double se_mean_new = se_full / (double)R;
     // slice row for the drift: L2-resident table reads, issued after the row loop to keep its
     // register footprint small (agents/common.py:9-65 needs message_size, buffer_size, buffer_latency)
     int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
@@ -630,9 +740,7 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
     p.st.queue_pkts[su] = total; p.st.queue_age_sum[su] = sum_age;
     p.st.front[su] = front; p.st.front_rem[su] = front_rem; p.st.fifo[su] = fifo;
     p.st.win_sent[su] = win_sent; p.st.win_dropped[su] = win_drop;
-    p.st.se_mean[su] = se_mean_new;
     p.st.pkt_effective_thr[su] = (int32_t)sent; p.st.dropped_pkts[su] = (int32_t)dropped;
-    if (MODE != MODE_STEP || slc < 0) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
     if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
         p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
     }
@@ -681,7 +789,7 @@ __global__ void __launch_bounds__(NT) ranenv_core_kernel(const KP p)
 }
 
 // =============================================================================================
-// Kernel 3/3  obs: one workgroup = one env, thread = (sorted slice position = tid / 16, UE slot).
+// Kernel 4/4  obs: one workgroup = one env, thread = (sorted slice position = tid / 16, UE slot).
 //   calculate_slice_ue_obs agents/common.py:343-378, IBSched.obs_space_format
 //   agents/ib_sched.py:91-200, calculate_reward :206-221 + common.py:381-439, and the per-env
 //   bookkeeping of CommunicationEnv.step (step counter, window length, trace positions, done).
@@ -863,7 +971,7 @@ struct ranenv {
     int cache_next = 0;
     bool use_graph = true;
     bool prof_on = false;               // ranenv_step_profiled: events around each kernel
-    hipEvent_t prof_ev[4] = {};
+    hipEvent_t prof_ev[5] = {};
     std::string err;
 };
 
@@ -902,34 +1010,25 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
     return RANENV_OK;
 }
 
-template <int MODE>
-void launch_core(ranenv_handle h, const KP &kp, int n_env, hipStream_t stream)
-{
-    const dim3 grid(n_env), block(h->nt);
-    switch (h->nt) {
-    case 64:   hipLaunchKernelGGL((ranenv_core_kernel<MODE, 64>), grid, block, 0, stream, kp); break;
-    case 128:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 128>), grid, block, 0, stream, kp); break;
-    case 256:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 256>), grid, block, 0, stream, kp); break;
-    case 512:  hipLaunchKernelGGL((ranenv_core_kernel<MODE, 512>), grid, block, 0, stream, kp); break;
-    default:   hipLaunchKernelGGL((ranenv_core_kernel<MODE, 1024>), grid, block, 0, stream, kp); break;
-    }
-}
-
-// One TTI of envs [e0, e0 + n_env) = alloc -> core -> obs on one stream (reset / dense skip alloc).
+// One TTI of envs [e0, e0 + n_env) = alloc -> stream -> ue -> obs on one stream (reset / dense skip alloc).
 template <int MODE>
 void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
 {
     kp.e0 = e0;
     const dim3 sblock((unsigned)(((kp.S * GRP) + WAVE - 1) / WAVE * WAVE));   // one thread per slot
+    const dim3 rblock((unsigned)h->nt);                                       // two threads per UE
+    const long long n_ue = (long long)n_env * kp.U;
     hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;       // diagnostic per-kernel timing
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[1], stream);
-    launch_core<MODE>(h, kp, n_env, stream);
+    hipLaunchKernelGGL((ranenv_stream_kernel<MODE>), dim3(n_env), rblock, 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL((ranenv_ue_kernel<MODE>), dim3((unsigned)((n_ue + 255) / 256)), dim3(256), 0, stream, kp, n_env);
+    if (ev) (void)hipEventRecord(ev[3], stream);
     if (MODE == MODE_RESET) hipLaunchKernelGGL((ranenv_obs_kernel<MODE_RESET>), dim3(n_env), sblock, 0, stream, kp);
     else hipLaunchKernelGGL((ranenv_obs_kernel<MODE_STEP>), dim3(n_env), sblock, 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    if (ev) (void)hipEventRecord(ev[4], stream);
 }
 
 // Fork the caller's stream into the chunk streams and join them back.
@@ -1064,7 +1163,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.tab.ue_max_pkts, NS * U); ALLOC(kp.tab.ue_max_age, NS * U);
     ALLOC(kp.st.queue_pkts, B * U); ALLOC(kp.st.queue_age_sum, B * U); ALLOC(kp.st.front, B * U);
     ALLOC(kp.st.front_rem, B * U); ALLOC(kp.st.fifo, B * U); ALLOC(kp.st.win_sent, B * U); ALLOC(kp.st.win_dropped, B * U);
-    ALLOC(kp.st.se_mean, B * U);
+    ALLOC(kp.st.se_mean, B * U); ALLOC(kp.st.se_part, B * U);
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
     ALLOC(kp.st.hist_len, B); ALLOC(kp.st.n_push, B); ALLOC(kp.st.step_no, B);
     ALLOC(kp.st.se_pos, B); ALLOC(kp.st.trf_pos, B);
@@ -1082,7 +1181,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
-    h->nt = U <= 64 ? 64 : U <= 128 ? 128 : U <= 256 ? 256 : U <= 512 ? 512 : 1024;
+    h->nt = (2 * U + WAVE - 1) / WAVE * WAVE;   // stream kernel: two lanes per UE
+    if (h->nt > 256) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build streams at most 128 UEs per env"); }
     h->lds_bytes = GRP * 4 * GRP * 8 + 3 * GRP * 8;   // static LDS of the widest kernel (obs)
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
@@ -1341,8 +1441,8 @@ int ranenv_step_profiled(ranenv_handle h, float *ms3, void *stream_)
     launch_chunk<MODE_STEP>(h, kp, 0, kp.B, stream);
     h->prof_on = false;
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventSynchronize(h->prof_ev[3]));
-    for (int k = 0; k < 3; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
+    HIP_TRY(h, hipEventSynchronize(h->prof_ev[4]));
+    for (int k = 0; k < 4; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
     return RANENV_OK;
 }
 

@@ -1,0 +1,97 @@
+// Microbenchmark: how fast can one MI355X stream [tile][R][U] float32 tiles with different load shapes?
+//   A: lane = UE, one dword per row per lane (the env-step pattern), DEPTH rows in flight
+//   B: lane = (UE quad, row mod 8), one dwordx4 per 8-row group per lane
+//   C: flat float4 copy-reduce of the same bytes (upper bound)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int DEPTH>
+__global__ void __launch_bounds__(128) kA(const float *pool, const int *tile_of, float *out, int U, int R)
+{
+    const float *tile = pool + (size_t)tile_of[blockIdx.x] * U * R;
+    const int u = threadIdx.x < U ? threadIdx.x : U - 1;
+    float acc = 0.f;
+    float q[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) q[d] = tile[(size_t)d * U + u];
+    for (int r = 0; r < R; r += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (r + d < R) {
+                acc += q[d];
+                const int rn = r + d + DEPTH;
+                if (rn < R) q[d] = tile[(size_t)rn * U + u];
+            }
+        }
+    }
+    if (threadIdx.x < U) out[(size_t)blockIdx.x * U + u] = acc;
+}
+
+template <int DEPTH>
+__global__ void __launch_bounds__(256) kB(const float *pool, const int *tile_of, float *out, int U, int R)
+{
+    const float *tile = pool + (size_t)tile_of[blockIdx.x] * U * R;
+    const int C = U / 4;
+    int c = threadIdx.x >> 3; const int j = threadIdx.x & 7;
+    const bool act = c < C; if (!act) c = C - 1;
+    const int G = R / 8;
+    float4 q[DEPTH];
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) if (d < G) q[d] = *(const float4 *)(tile + (size_t)(d * 8 + j) * U + 4 * c);
+    for (int g = 0; g < G; g += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (g + d < G) {
+                acc.x += q[d].x; acc.y += q[d].y; acc.z += q[d].z; acc.w += q[d].w;
+                const int gn = g + d + DEPTH;
+                if (gn < G) q[d] = *(const float4 *)(tile + (size_t)(gn * 8 + j) * U + 4 * c);
+            }
+        }
+    }
+    if (act) out[(size_t)blockIdx.x * U + 4 * c + (j & 3)] = acc.x + acc.y + acc.z + acc.w;
+}
+
+__global__ void __launch_bounds__(256) kC(const float4 *pool, const int *tile_of, float *out, int n4)
+{
+    const float4 *tile = pool + (size_t)tile_of[blockIdx.x] * n4;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256 * 4) {
+        float4 a = tile[i], b = i + 256 < n4 ? tile[i + 256] : make_float4(0, 0, 0, 0);
+        float4 c = i + 512 < n4 ? tile[i + 512] : make_float4(0, 0, 0, 0), d = i + 768 < n4 ? tile[i + 768] : make_float4(0, 0, 0, 0);
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+    }
+    if (acc == 12345.f) out[blockIdx.x] = acc;
+}
+
+int main()
+{
+    const int U = 100, R = 135, B = 4096, T = 40000;
+    float *pool; int *tile_of; float *out;
+    CK(hipMalloc(&pool, (size_t)T * U * R * 4));
+    CK(hipMemset(pool, 0, (size_t)T * U * R * 4));
+    CK(hipMalloc(&tile_of, B * 4)); CK(hipMalloc(&out, (size_t)B * U * 4));
+    std::vector<int> h(B);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double bytes = (double)B * U * R * 4;
+    auto run = [&](const char *name, auto launch) {
+        float best = 1e9f;
+        for (int it = 0; it < 12; it++) {
+            for (int b = 0; b < B; b++) h[b] = (int)(((long long)b * 9973 + it * 7919) % T);
+            hipMemcpy(tile_of, h.data(), B * 4, hipMemcpyHostToDevice);
+            hipEventRecord(e0, 0); launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 1 && ms < best) best = ms;
+        }
+        printf("%-28s %8.1f us  %6.2f TB/s\n", name, best * 1e3, bytes / (best * 1e-3) / 1e12);
+    };
+    run("A dword lane=UE depth 8", [&] { hipLaunchKernelGGL(kA<8>, dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("A dword lane=UE depth 16", [&] { hipLaunchKernelGGL(kA<16>, dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("A dword lane=UE depth 32", [&] { hipLaunchKernelGGL(kA<32>, dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("B dwordx4 quad x row8 d2", [&] { hipLaunchKernelGGL(kB<2>, dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
+    run("B dwordx4 quad x row8 d4", [&] { hipLaunchKernelGGL(kB<4>, dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
+    run("B dwordx4 quad x row8 d8", [&] { hipLaunchKernelGGL(kB<8>, dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
+    run("C flat float4", [&] { hipLaunchKernelGGL(kC, dim3(B), dim3(256), 0, 0, (const float4 *)pool, tile_of, out, U * R / 4); });
+    return 0;
+}
