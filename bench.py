@@ -148,16 +148,16 @@ def main():
         elapsed = float(tmax.item())
     step_ms = ev_start.elapsed_time(ev_end) / args.steps      # device time of one TTI (3 kernels)
     prof = [env.step_profiled() for _ in range(24)][4:]       # per-kernel HIP events, after the timed region
-    kms = {k: float(np.mean([q[k] for q in prof])) for k in ("alloc", "stream", "ue", "obs")}
+    kms = {k: float(np.mean([q[k] for q in prof])) for k in ("alloc", "core")}
     total_env_steps = batch * world * args.steps
     value = total_env_steps / elapsed
 
     if rank == 0:
         alg_bytes = env.algorithmic_bytes_per_env_step() * batch          # per TTI of the whole batch
         achieved = alg_bytes / (step_ms * 1e-3) / 1e9                     # whole step: alloc + core + obs
-        # the dominant kernel (stream) reads the SE tile: 4*U*R bytes of SURVEY 8(d)'s per-env figure
-        core_bytes = 4 * env.U * env.R * batch
-        core_gbs = core_bytes / (kms["stream"] * 1e-3) / 1e9
+        # the dominant kernel (core) moves everything except the action term of SURVEY 8(d)
+        core_bytes = (env.algorithmic_bytes_per_env_step() - env.S * 5) * batch
+        core_gbs = core_bytes / (kms["core"] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -179,13 +179,13 @@ def main():
                        "n_rbs": env.R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "one TTI = ranenv_alloc_kernel + ranenv_stream_kernel + ranenv_ue_kernel + ranenv_obs_kernel",
+                         "kernel": "one TTI = ranenv_alloc_kernel + ranenv_core_kernel<STEP>",
                          "kernel_ms": step_ms,
                          "algorithmic_bytes_per_env_step": env.algorithmic_bytes_per_env_step(),
-                         "dominant_kernel": {"name": "ranenv_stream_kernel<STEP>", "ms": kms["stream"],
+                         "dominant_kernel": {"name": "ranenv_core_kernel<STEP>", "ms": kms["core"],
                                              "algorithmic_bytes": core_bytes, "achieved": core_gbs,
                                              "frac": core_gbs / HBM_PEAK_GBS},
-                         "other_kernels_ms": {"alloc": kms["alloc"], "ue": kms["ue"], "obs": kms["obs"]}},
+                         "other_kernels_ms": {"alloc": kms["alloc"]}},
             "metrics": summarize(gathered.cpu()),
         }
         if world == 1 and not args.no_cpu_baseline:

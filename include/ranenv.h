@@ -199,8 +199,8 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       void *stream);
 
 /* Diagnostic: one TTI (device policy, bound pools, no observation outputs) with HIP events
- * around each kernel; blocks until it finished.  ms4 = {alloc, stream, ue, obs} durations in ms. */
-int ranenv_step_profiled(ranenv_handle h, float *ms4, void *stream);
+ * around each kernel; blocks until it finished.  ms2 = {alloc, core} durations in ms. */
+int ranenv_step_profiled(ranenv_handle h, float *ms2, void *stream);
 
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 

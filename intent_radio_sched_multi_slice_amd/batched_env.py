@@ -255,10 +255,10 @@ class BatchedRanEnv:
         }
 
     def step_profiled(self):
-        """Diagnostic: one TTI with HIP events around each kernel -> {'alloc','stream','ue','obs'} in ms."""
+        """Diagnostic: one TTI with HIP events around each kernel -> {'alloc','core'} in ms."""
         ms = (C.c_float * 4)()
         self._check(self._lib.ranenv_step_profiled(self._h, ms, self._stream()), "ranenv_step_profiled")
-        return {"alloc": ms[0], "stream": ms[1], "ue": ms[2], "obs": ms[3]}
+        return {"alloc": ms[0], "core": ms[1]}
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -571,19 +571,152 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
     if (in_grid) p.st.slot_rbc[(size_t)e * NS16 + tid] = count;
 }
 
-// =============================================================================================
-// Kernel 2/4  stream: two lanes per UE reduce that UE's SE row (mean over all RBs, sum over its
-//   allocated RBs).  Nothing else: no LDS, no barriers, ~70 VGPRs, every resident wave streams.
-// =============================================================================================
-constexpr int STREAM_NT_MAX = 1024;
+// ---------------------------------------------------------------------------------------------
+// SE row reduction, 16 B per lane: lane (c, j) of an env loads, for every group of 8 RBs, the float4
+// of RB 8g + j and UEs 4c..4c+3.  Lane j therefore IS numpy's accumulator j for those four UEs, and
+// the leaf result ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is an xor-butterfly over the 8 lanes of a quad.
+// A wave-level load covers eight 128-byte row segments; measured on MI355X this shape streams at
+// 5.3 TB/s where one dword per lane and row stops at 2.6 TB/s (tools/bw_probe.hip).
+// ---------------------------------------------------------------------------------------------
+constexpr int SE4_DEPTH = 4;
 
-template <int MODE>
-__global__ void __launch_bounds__(256) ranenv_stream_kernel(const KP p)
+struct SeStream4 {
+    float4 q[SE4_DEPTH];
+    __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile; out-of-range reads return 0
+    int U, c4, j;
+
+    DEVFN float4 load_row(int row)
+    {
+        const int off = (row * U + c4) * 4;     // per-lane byte offset: 17 loads per lane and TTI
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return __builtin_bit_cast(float4, v);
+    }
+    DEVFN void init(const float *tile, int U_, int c, int j_, int R)
+    {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U_ * R * 4, 0x00020000);
+        U = U_; c4 = 4 * c; j = j_;
+        const int G = R >> 3;
+#pragma unroll
+        for (int d = 0; d < SE4_DEPTH; d++) if (d < G) q[d] = load_row(d * 8 + j);
+    }
+};
+
+// full[k] / part[k] for the quad's UE k: sum over all RBs / over the RBs selected by in(k, r).
+// All 8 lanes of a quad return the same values.
+// SMALL: R <= 256, i.e. at most two leaves (left, right): four fewer register quads.
+template <bool SMALL, typename InFn>
+DEVFN void row_sums4(SeStream4 &st, int R, InFn in, double (&full)[4], double (&part)[4])
 {
+    const RowPlan pl = make_row_plan(R);
+    const int tail = R & 7, G = R >> 3, j = st.j;
+    double f[4] = {0.0, 0.0, 0.0, 0.0}, g[4] = {0.0, 0.0, 0.0, 0.0};
+    double fr[4] = {0.0, 0.0, 0.0, 0.0}, gr[4] = {0.0, 0.0, 0.0, 0.0};
+    double lf[4], lg[4], rf[SMALL ? 1 : 4], rg[SMALL ? 1 : 4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { lf[k] = lg[k] = 0.0; if (!SMALL) { rf[k] = rg[k] = 0.0; } }
+    int leaf = 0, left_in_leaf = pl.len0 >> 3;            // wave-uniform cursor
+    auto fold = [&](int lk) {
+        if (SMALL) {        // leaf 0 is the left half; leaf 1 (the right half) stays in fr/gr
+            if (lk == 0 && pl.n_leaves > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { lf[k] = fr[k]; lg[k] = gr[k]; }
+            }
+            return;
+        }
+        const bool left = pl.lsplit ? (lk < 2) : (lk < 1);
+        const bool first = pl.lsplit ? (lk == 0 || lk == 2) : (lk <= 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (left) { if (first) { lf[k] = fr[k]; lg[k] = gr[k]; } else { lf[k] = lf[k] + fr[k]; lg[k] = lg[k] + gr[k]; } }
+            else      { if (first) { rf[k] = fr[k]; rg[k] = gr[k]; } else { rf[k] = rf[k] + fr[k]; rg[k] = rg[k] + gr[k]; } }
+        }
+    };
+    auto add_row = [&](const float4 &v, int row, double (&af)[4], double (&ag)[4]) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float xs = in(k, row) ? x[k] : 0.0f;
+            af[k] += (double)x[k];
+            ag[k] += (double)xs;
+        }
+    };
+    auto consume = [&](const float4 &v, int g0) {
+        add_row(v, g0 * 8 + j, f, g);
+        if (--left_in_leaf == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {            // numpy's tree = xor-butterfly over the quad's 8 lanes
+                double a = f[k], b2 = g[k];
+                a += __shfl_xor(a, 1); b2 += __shfl_xor(b2, 1);
+                a += __shfl_xor(a, 2); b2 += __shfl_xor(b2, 2);
+                a += __shfl_xor(a, 4); b2 += __shfl_xor(b2, 4);
+                fr[k] = a; gr[k] = b2; f[k] = 0.0; g[k] = 0.0;
+            }
+            if (!(leaf == pl.n_leaves - 1 && tail > 0)) fold(leaf);
+            leaf += 1;
+            left_in_leaf = ((leaf == 1) * pl.len1 + (leaf == 2) * pl.len2 + (leaf == 3) * pl.len3) >> 3;
+        }
+    };
+#pragma unroll 1
+    for (int gi = 0; gi < G; gi += SE4_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < SE4_DEPTH; d++) {
+            if (gi + d < G) {
+                consume(st.q[d], gi + d);
+                if (gi + d + SE4_DEPTH < G) st.q[d] = st.load_row((gi + d + SE4_DEPTH) * 8 + j);
+            }
+        }
+    }
+    if (tail > 0) {
+        if (G == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { fr[k] = 0.0; gr[k] = 0.0; }   // n < 8: numpy's plain loop from 0.0
+        }
+        float4 tl[7];              // the tail rows are the same for the 8 lanes of a quad
+#pragma unroll
+        for (int t = 0; t < 7; t++) tl[t] = t < tail ? st.load_row(G * 8 + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 7; t++) if (t < tail) add_row(tl[t], G * 8 + t, fr, gr);
+        fold(pl.n_leaves - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (SMALL) {           // one leaf: the row sum is fr; two leaves: left + right
+            full[k] = pl.n_leaves == 1 ? fr[k] : lf[k] + fr[k];
+            part[k] = pl.n_leaves == 1 ? gr[k] : lg[k] + gr[k];
+        } else {
+            full[k] = pl.n_leaves == 1 ? lf[k] : lf[k] + rf[k];
+            part[k] = pl.n_leaves == 1 ? lg[k] : lg[k] + rg[k];
+        }
+    }
+}
+
+// =============================================================================================
+// Kernel 2/2  core: one workgroup = one env, three roles in sequence
+//   (1) stream   thread = (UE quad, RB mod 8): SE row sums, 16 B loads, no LDS until the hand-off
+//   (2) UE step  thread = UE: capacity -> UEs.step -> 10-TTI window -> intent drift
+//                (oracle/ranenv_oracle.c; agents/common.py:68-340); its state loads are issued at
+//                kernel entry and land under the stream
+//   (3) obs      thread = slice (sorted position), threads 0..15: calculate_slice_ue_obs
+//                agents/common.py:343-378, IBSched.obs_space_format agents/ib_sched.py:91-200,
+//                calculate_reward :206-221 + common.py:381-439, per-env bookkeeping
+// =============================================================================================
+struct SharedCore {
+    double se_full[ALLOC_NT], se_part[ALLOC_NT];   // hand-off (1) -> (2), indexed by UE
+    double rows[GRP][4][GRP];                      // hand-off (2) -> (3): drift x3, mean SE by [slice][metric][pos]
+    double xr[3][GRP];
+    int cnt[GRP][GRP];                             // RBs of each slot
+};
+
+template <int MODE, bool SMALL, bool QUADS>
+__global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
+{
+    __shared__ SharedCore sh;
+    auto &rows = sh.rows; auto &xr = sh.xr;
     const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
     if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
-    const int U = p.U, R = p.R;
+    const int S = p.S, U = p.U, R = p.R, D = p.D, Us = p.Us;
+    const int W = 2 * Us + 9;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto uni64 = [](long long v) {
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -591,76 +724,56 @@ __global__ void __launch_bounds__(256) ranenv_stream_kernel(const KP p)
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
     };
     ranenv_episode ep = p.episodes[e];
-    ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.se_base = uni64(ep.se_base);
+    ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
+    ep.se_len = uni(ep.se_len); ep.trf_len = uni(ep.trf_len);
+    ep.se_base = uni64(ep.se_base); ep.trf_base = uni64(ep.trf_base);
     const int sc = ep.scenario;
+    const int t = (MODE == MODE_RESET) ? 0 : uni(p.st.step_no[e]);
+    int hlen = uni(p.st.hist_len[e]);
+    const int npush = uni(p.st.n_push[e]);                    // kept in [0, D)
     const int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[e]);
+    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[e]);
+    const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
+    if (clear_hist) hlen = 0;
+    const int hlen_new = hlen < D ? hlen + 1 : D;
     const float *tile;
     if (p.se_tiles != nullptr) tile = p.se_tiles + (size_t)e * U * R;
     else tile = p.se_pool + (size_t)(ep.se_base + (long long)se_pos) * (size_t)p.se_stride;
 
-    const int ur = tid >> 1, h = tid & 1;
-    const bool act = ur < U;
-    const int u = act ? ur : U - 1;           // idle lanes shadow the last UE (loads stay in bounds)
-    SeStream2 se;
-    se.init(tile, U, u, h, R);                // 24 + tail loads in flight from here on
-    const size_t su = (size_t)e * U + u;
-    double se_full = 0.0, se_part = 0.0;
-    int rb_start = 0, rb_count = 0;
-    if (MODE == MODE_STEP) {
-        if (p.tab.ue_slice[(size_t)sc * U + u] >= 0) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
-        const unsigned ust = (unsigned)rb_start, ucn = (unsigned)rb_count;
-        row_sums2(se, R, h, [=](int r) { return ((unsigned)r - ust) < ucn; }, se_full, se_part);
-    } else if (MODE == MODE_DENSE) {
-        const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-        row_sums2(se, R, h, [=](int r) { return mrow[r] != 0; }, se_full, se_part);
-        bool seen = false;
-        for (int r = 0; r < R; r++) {
-            if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
+    // ---- (1) stream role: issue the SE loads first ------------------------------------------------
+    const int C = (U + 3) >> 2;
+    const int qc = tid >> 3, qj = tid & 7;
+    const bool sact = qc < C;
+    SeStream4 se;
+    SeStream se1;
+    unsigned ust[4] = {0, 0, 0, 0}, ucn[4] = {0, 0, 0, 0};
+    if (QUADS) {
+        se.init(tile, U, sact ? qc : C - 1, qj, R);
+        if (MODE == MODE_STEP) {   // RB ranges of the quad's UEs (0 for UEs outside every slice: zeroed at reset)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int uq = se.c4 + k;
+                if (uq < U) { ust[k] = (unsigned)p.st.rb_start[(size_t)e * U + uq]; ucn[k] = (unsigned)p.st.rb_count[(size_t)e * U + uq]; }
+            }
         }
     } else {
-        row_sums2(se, R, h, [](int) { return false; }, se_full, se_part);
+        se1.init(tile, U, tid < U ? tid : U - 1, R);   // lane = UE: one dword per RB
     }
-    if (act && h == 0) {
-        p.st.se_mean[su] = se_full / (double)R;
-        p.st.se_part[su] = se_part;
-        if (MODE != MODE_STEP || rb_count == 0) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
-    }
-}
 
-// =============================================================================================
-// Kernel 3/4  ue: lane = (env, UE), flat.  Capacity -> UEs.step -> 10-TTI window -> intent drift.
-//   UEs.step / Buffer: oracle/ranenv_oracle.c (sixg_radio_mgmt is un-vendored);
-//   intent_drift_calc agents/common.py:68-340.
-// =============================================================================================
-template <int MODE>
-__global__ void __launch_bounds__(256) ranenv_ue_kernel(const KP p, const int n_env)
-{
-    const int S = p.S, U = p.U, D = p.D;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)n_env * U) return;
-    const int e = p.e0 + (int)(idx / U), u = (int)(idx % U);
-    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;
-    const ranenv_episode ep = p.episodes[e];
-    const int sc = ep.scenario;
-    const int t = (MODE == MODE_RESET) ? 0 : p.st.step_no[e];
-    int hlen = p.st.hist_len[e];
-    const int npush = p.st.n_push[e];                         // kept in [0, D)
-    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : p.st.trf_pos[e];
-    const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
-    if (clear_hist) hlen = 0;
-    const int hlen_new = hlen < D ? hlen + 1 : D;
-
+    // ---- (2) UE role: everything this UE needs, issued now so that it lands under the stream -----
+    const bool act = tid < U;
+    const int u = act ? tid : U - 1;
     const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
     const int slc = p.tab.ue_slice[tu], ue_pos = p.tab.ue_pos[tu];
     const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
-    int total = 0, front = 0, front_rem = 0, fifo = 0;
+    int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     if (MODE != MODE_RESET) {
         total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
         front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
     }
     if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
-    const int rb_count = p.st.rb_count[su];
+    if (MODE == MODE_STEP) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
     int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
     int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
@@ -668,170 +781,180 @@ __global__ void __launch_bounds__(256) ranenv_ue_kernel(const KP p, const int n_
     double traffic = 0.0;
     if (MODE != MODE_RESET)
         traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
-    const double se_mean_new = p.st.se_mean[su], se_part = p.st.se_part[su];
     const double occ_prev = (double)total / (double)max_pkts;
-    // slice row for the drift: L2-resident table reads, issued after the row loop to keep its
-    // register footprint small (agents/common.py:9-65 needs message_size, buffer_size, buffer_latency)
-    int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
-    int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
-    double pv[3] = {0.0, 0.0, 0.0};
-    if (slc >= 0) {
-        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
-        has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
-            po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
-            pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
+    // zero the (2) -> (3) rows
+    for (int i = tid; i < GRP * 4 * GRP; i += (int)blockDim.x) (&rows[0][0][0])[i] = 0.0;
+    for (int i = tid; i < GRP * GRP; i += (int)blockDim.x) (&sh.cnt[0][0])[i] = 0;
+
+    // ---- (1) SE row sums -------------------------------------------------------------------------
+    double my_full = 0.0, my_part = 0.0;
+    if (QUADS) {
+        double sfull[4], spart[4];
+        if (MODE == MODE_STEP) {
+            row_sums4<SMALL>(se, R, [&](int k, int r) { return ((unsigned)r - ust[k]) < ucn[k]; }, sfull, spart);
+        } else if (MODE == MODE_DENSE) {
+            const uint8_t *mbase = p.dense + (size_t)e * U * R;
+            const int c4 = se.c4;
+            row_sums4<SMALL>(se, R, [&](int k, int r) { const int uq = c4 + k < U ? c4 + k : U - 1; return mbase[(size_t)uq * R + r] != 0; }, sfull, spart);
+        } else {
+            row_sums4<SMALL>(se, R, [](int, int) { return false; }, sfull, spart);
         }
+        if (sact && qj == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (se.c4 + k < U) { sh.se_full[se.c4 + k] = sfull[k]; sh.se_part[se.c4 + k] = spart[k]; }
+        }
+        __syncthreads();
+        my_full = sh.se_full[u]; my_part = sh.se_part[u];
+    } else {
+        if (MODE == MODE_STEP) {
+            const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
+            row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part);
+        } else if (MODE == MODE_DENSE) {
+            const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
+            row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part);
+        } else {
+            row_sums(se1, R, [](int) { return false; }, my_full, my_part);
+        }
+        __syncthreads();        // the (2) -> (3) rows were zeroed above by all threads
     }
 
-    // ---- UEs.step (oracle/ranenv_oracle.c buffer_receive / buffer_send) ---------------------------
-    long long dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;
-    if (MODE != MODE_RESET) {
-        const double psz = (double)pkt_size;
-        // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
-        pkt_thr = (int)((se_part * p.bw_per_rb) / psz);
-        pkt_in = (int)(traffic / psz);
-        const int L = p.L;
-        // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of (arrival TTI,
-        // packets) entries in arrival order.  ring[k] holds entry k of a circular list (head index +
-        // entry count per UE); only TTIs that admitted packets make an entry, so expiring / draining
-        // costs one load per consumed entry and never a scan.
-        int2 *ring = p.st.age_ring + (size_t)e * L * U + u;
-        int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
-        auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
-        auto load_head = [&]() { const int2 en = ring[(size_t)head * U]; front = en.x; front_rem = en.y; };
-        if (nent > 0 && front == t - max_age - 1) {         // receive: the bin older than max_age expires
-            dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
-            front_rem = 0;
-            pop_head();
-            if (nent > 0) load_head();
+    // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
+    if (act) {
+        if (MODE == MODE_DENSE) {
+            const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
+            bool seen = false;
+            for (int r = 0; r < R; r++) {
+                if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
+            }
         }
-        sum_age += total;                                     // everything left ages one TTI
-        const long long space = (long long)max_pkts - total;  // arrivals admitted up to capacity
-        const long long adm = pkt_in < space ? pkt_in : space;
-        dropped += pkt_in - adm;
-        if (adm > 0) {
-            int tail = head + nent; tail = tail >= L ? tail - L : tail;
-            ring[(size_t)tail * U] = make_int2(t, (int)adm);
-            if (nent == 0) { front = t; front_rem = (int)adm; }
-            nent++;
-            total += (int)adm;
-        }
-        long long cap = pkt_thr;                              // send: drain oldest first
-        while (cap > 0 && nent > 0) {
-            const long long take = cap < front_rem ? cap : front_rem;
-            front_rem -= (int)take; total -= (int)take; cap -= take; sent += take;
-            sum_age -= (long long)(t - front) * take;
-            if (front_rem == 0) {
+        const double se_mean_new = my_full / (double)R, se_part = my_part;
+        long long dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;
+        if (MODE != MODE_RESET) {
+            const double psz = (double)pkt_size;
+            // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
+            pkt_thr = (int)((se_part * p.bw_per_rb) / psz);
+            pkt_in = (int)(traffic / psz);
+            const int L = p.L;
+            // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of (arrival TTI,
+            // packets) entries in arrival order.  ring[k] holds entry k of a circular list (head index +
+            // entry count per UE); only TTIs that admitted packets make an entry, so expiring / draining
+            // costs one load per consumed entry and never a scan.
+            int2 *ring = p.st.age_ring + (size_t)e * L * U + u;
+            int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
+            auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
+            auto load_head = [&]() { const int2 en = ring[(size_t)head * U]; front = en.x; front_rem = en.y; };
+            if (nent > 0 && front == t - max_age - 1) {         // receive: the bin older than max_age expires
+                dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
+                front_rem = 0;
                 pop_head();
-                if (nent > 0) {
-                    if (nent == 1 && adm > 0) { front = t; front_rem = (int)adm; }   // this TTI's entry
-                    else load_head();
+                if (nent > 0) load_head();
+            }
+            sum_age += total;                                     // everything left ages one TTI
+            const long long space = (long long)max_pkts - total;  // arrivals admitted up to capacity
+            const long long adm = pkt_in < space ? pkt_in : space;
+            dropped += pkt_in - adm;
+            if (adm > 0) {
+                int tail = head + nent; tail = tail >= L ? tail - L : tail;
+                ring[(size_t)tail * U] = make_int2(t, (int)adm);
+                if (nent == 0) { front = t; front_rem = (int)adm; }
+                nent++;
+                total += (int)adm;
+            }
+            long long cap = pkt_thr;                              // send: drain oldest first
+            while (cap > 0 && nent > 0) {
+                const long long take = cap < front_rem ? cap : front_rem;
+                front_rem -= (int)take; total -= (int)take; cap -= take; sent += take;
+                sum_age -= (long long)(t - front) * take;
+                if (front_rem == 0) {
+                    pop_head();
+                    if (nent > 0) {
+                        if (nent == 1 && adm > 0) { front = t; front_rem = (int)adm; }   // this TTI's entry
+                        else load_head();
+                    }
+                }
+            }
+            fifo = head | (nent << 16);
+        }
+        // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
+        win_sent += sent - old_s; win_drop += dropped - old_d;
+        *rs = (int32_t)sent; *rd = (int32_t)dropped;
+        p.st.queue_pkts[su] = total; p.st.queue_age_sum[su] = sum_age;
+        p.st.front[su] = front; p.st.front_rem[su] = front_rem; p.st.fifo[su] = fifo;
+        p.st.win_sent[su] = win_sent; p.st.win_dropped[su] = win_drop;
+        p.st.pkt_effective_thr[su] = (int32_t)sent; p.st.dropped_pkts[su] = (int32_t)dropped;
+        if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
+            p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
+        }
+
+        p.st.se_mean[su] = se_mean_new;
+        if (MODE != MODE_STEP) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
+        const double occ_new = (double)total / (double)max_pkts;
+        const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
+        // slice row for the drift: L2-resident table reads
+        int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
+        int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
+        double pv[3] = {0.0, 0.0, 0.0};
+        if (slc >= 0) {
+            const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
+            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
+                po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
+                pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
+            }
+        }
+        // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
+        double dres[3] = {0.0, 0.0, 0.0};
+        if (slc >= 0 && has_req) {
+            const double o = p.over;
+    #pragma unroll
+            for (int qi = 0; qi < 3; qi++) {
+                if (qi < npar) {
+                    const int metric = pm[qi], op = po[qi];
+                    const double value = pv[qi];
+                    double res;
+                    if (metric == RANENV_METRIC_THROUGHPUT) {
+                        double x = ((double)sent * (double)msg) / 1e6;                  // common.py:25-31
+                        bool zero = d_isclose(occ_new, 0.0);                            // :100-119
+                        if (hlen_new > 1) zero = zero || d_isclose(occ_prev, 0.0);
+                        if (zero) x = value * (1.1 + o);
+                        if (d_apply_op(op, x, value)) res = (x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o);
+                        else res = -((value - x) / value);
+                    } else if (metric == RANENV_METRIC_RELIABILITY) {
+                        const double dw = (double)win_drop, sw = (double)win_sent;      // :32-53
+                        const double buffer_pkts = occ_new * (double)bsize + dw + sw;
+                        const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
+                        const double band = (100.0 - value) / 100.0;
+                        if (d_apply_op(op, 100.0 * (1.0 - x), value)) res = (x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o);
+                        else res = -((x - band) / (value / 100.0));
+                    } else {
+                        const double x = lat_new;                                       // :58-61
+                        if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
+                        else res = -((x - value) / ((double)blat - value));
+                    }
+                    dres[metric] = res;
                 }
             }
         }
-        fifo = head | (nent << 16);
-    }
-    // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
-    win_sent += sent - old_s; win_drop += dropped - old_d;
-    *rs = (int32_t)sent; *rd = (int32_t)dropped;
-    p.st.queue_pkts[su] = total; p.st.queue_age_sum[su] = sum_age;
-    p.st.front[su] = front; p.st.front_rem[su] = front_rem; p.st.fifo[su] = fifo;
-    p.st.win_sent[su] = win_sent; p.st.win_dropped[su] = win_drop;
-    p.st.pkt_effective_thr[su] = (int32_t)sent; p.st.dropped_pkts[su] = (int32_t)dropped;
-    if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
-        p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
-    }
-    const double occ_new = (double)total / (double)max_pkts;
-    const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
 
-    // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
-    double dres[3] = {0.0, 0.0, 0.0};
-    if (slc >= 0 && has_req) {
-        const double o = p.over;
-#pragma unroll
-        for (int qi = 0; qi < 3; qi++) {
-            if (qi < npar) {
-                const int metric = pm[qi], op = po[qi];
-                const double value = pv[qi];
-                double res;
-                if (metric == RANENV_METRIC_THROUGHPUT) {
-                    double x = ((double)sent * (double)msg) / 1e6;                  // common.py:25-31
-                    bool zero = d_isclose(occ_new, 0.0);                            // :100-119
-                    if (hlen_new > 1) zero = zero || d_isclose(occ_prev, 0.0);
-                    if (zero) x = value * (1.1 + o);
-                    if (d_apply_op(op, x, value)) res = (x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o);
-                    else res = -((value - x) / value);
-                } else if (metric == RANENV_METRIC_RELIABILITY) {
-                    const double dw = (double)win_drop, sw = (double)win_sent;      // :32-53
-                    const double buffer_pkts = occ_new * (double)bsize + dw + sw;
-                    const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
-                    const double band = (100.0 - value) / 100.0;
-                    if (d_apply_op(op, 100.0 * (1.0 - x), value)) res = (x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o);
-                    else res = -((x - band) / (value / 100.0));
-                } else {
-                    const double x = lat_new;                                       // :58-61
-                    if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
-                    else res = -((x - value) / ((double)blat - value));
-                }
-                dres[metric] = res;
+        if (slc >= 0) {
+            // record for next TTI's alloc (slot-ordered) and rows for this TTI's observation
+            const size_t es = (size_t)e * (S * GRP) + slc * GRP + ue_pos;
+            p.st.slot_q[es] = total; p.st.slot_ws[es] = win_sent; p.st.slot_sem[es] = se_mean_new;
+            rows[slc][0][ue_pos] = dres[0]; rows[slc][1][ue_pos] = dres[1]; rows[slc][2][ue_pos] = dres[2];
+            rows[slc][3][ue_pos] = se_mean_new;
+            sh.cnt[slc][ue_pos] = rb_count;
+            if (p.obs_intra && ue_pos < Us) {                                          // per-UE entries (:186-200)
+                float *oa = p.obs_intra + ((size_t)e * S + slc) * W;
+                oa[9 + ue_pos] = (float)occ_new;
+                oa[9 + Us + ue_pos] = (float)(se_mean_new / p.norm_se);
             }
         }
-    }
-    if (slc >= 0) {   // slot-ordered record for alloc (next TTI) and obs (this TTI)
-        const size_t es = (size_t)e * (S * GRP) + slc * GRP + ue_pos;
-        p.st.slot_q[es] = total; p.st.slot_ws[es] = win_sent; p.st.slot_sem[es] = se_mean_new;
-        p.st.slot_d0[es] = dres[0]; p.st.slot_d1[es] = dres[1]; p.st.slot_d2[es] = dres[2];
-        if (MODE != MODE_STEP) p.st.slot_rbc[es] = rb_count;
-    }
-}
-
-// =============================================================================================
-// Kernel 4/4  obs: one workgroup = one env, thread = (sorted slice position = tid / 16, UE slot).
-//   calculate_slice_ue_obs agents/common.py:343-378, IBSched.obs_space_format
-//   agents/ib_sched.py:91-200, calculate_reward :206-221 + common.py:381-439, and the per-env
-//   bookkeeping of CommunicationEnv.step (step counter, window length, trace positions, done).
-// =============================================================================================
-template <int MODE>
-__global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
-{
-    __shared__ double rows[GRP][4][GRP];     // per-slice rows (by slice index): drift x3, mean SE
-    __shared__ double xr[3][GRP];            // cross-slice rows
-    __shared__ int sh_n[GRP], sh_rbs[GRP];
-    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
-    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
-    const int S = p.S, Us = p.Us, R = p.R, D = p.D;
-    const int W = 2 * Us + 9, NS16 = S * GRP;
-    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
-    // ---- every thread: one slot of the env's slot-ordered records (coalesced) ---------------------
-    const int sl = tid / GRP, pos = tid % GRP;              // (slice, position)
-    const bool in_grid = tid < NS16;
-    int ue = -1, q = 0, mp = 1, rbc = 0; double d0 = 0.0, d1 = 0.0, d2 = 0.0, sem = 0.0;
-    if (in_grid) {
-        const size_t ts = (size_t)sc * NS16 + tid, es = (size_t)e * NS16 + tid;
-        ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts];
-        q = p.st.slot_q[es]; sem = p.st.slot_sem[es]; rbc = p.st.slot_rbc[es];
-        d0 = p.st.slot_d0[es]; d1 = p.st.slot_d1[es]; d2 = p.st.slot_d2[es];
-    }
-    const bool have = ue >= 0;
-    rows[sl][0][pos] = have ? d0 : 0.0; rows[sl][1][pos] = have ? d1 : 0.0;
-    rows[sl][2][pos] = have ? d2 : 0.0; rows[sl][3][pos] = have ? sem : 0.0;
-    const int gsh = (tid & 63) & ~(GRP - 1);
-    const int n_grp = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));
-    int rsum = have ? rbc : 0;                                                     // :176-181 (exact integers)
-#pragma unroll
-    for (int d = 1; d < GRP; d <<= 1) rsum += __shfl_xor(rsum, d, GRP);
-    if (pos == 0) { sh_n[sl] = n_grp; sh_rbs[sl] = rsum; }
-    if (in_grid && p.obs_intra && pos < Us) {                                      // per-UE entries (:186-200)
-        float *oa = p.obs_intra + ((size_t)e * S + sl) * W;
-        oa[9 + pos] = have ? (float)((double)q / (double)mp) : 0.0f;
-        oa[9 + Us + pos] = have ? (float)(sem / p.norm_se) : 0.0f;
     }
     if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
     __syncthreads();
-    if (tid >= GRP) return;                  // the per-slice rows are done by threads 0..15 (one wave)
+    if (tid >= GRP) return;                  // (3) is done by threads 0..15 (one wave)
 
     // ---- thread t < 16: slice at sorted position t (ib_sched.py:91) --------------------------------
     const int spos = tid;
@@ -843,7 +966,10 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
         s = p.tab.slice_i32[((size_t)sc * S + spos) * 8 + 7];
         const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s) * 8;
         active = si[0];
-        const int has_req = si[1], npar = si[6], n = sh_n[s];
+        const int has_req = si[1], npar = si[6], n = si[2];
+        int rbs_s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) rbs_s += sh.cnt[s][k];
         priority_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 0];
         const double traffic_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 1];
         if (n > 0 && has_req) {                                                    // common.py:343-378
@@ -877,8 +1003,8 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_obs_kernel(const KP p)
         if (p.obs_intra) {
             float *oa = p.obs_intra + ((size_t)e * S + s) * W;
             oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
-            oa[6] = (float)((double)sh_rbs[s] / (double)R); oa[7] = tr; oa[8] = nu;
-            for (int k = GRP; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
+            oa[6] = (float)((double)rbs_s / (double)R); oa[7] = tr; oa[8] = nu;
+            for (int k = n; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
         }
         // player_{s+1} reward (common.py:428-437)
         double r = 0.0; int cnt = 0;
@@ -970,8 +1096,9 @@ struct ranenv {
     Cached cache[6];
     int cache_next = 0;
     bool use_graph = true;
+    bool quads = false;                 // core variant: float4 quads (true) or lane = UE dword stream
     bool prof_on = false;               // ranenv_step_profiled: events around each kernel
-    hipEvent_t prof_ev[5] = {};
+    hipEvent_t prof_ev[3] = {};
     std::string err;
 };
 
@@ -1010,25 +1137,24 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
     return RANENV_OK;
 }
 
-// One TTI of envs [e0, e0 + n_env) = alloc -> stream -> ue -> obs on one stream (reset / dense skip alloc).
+// One TTI of envs [e0, e0 + n_env) = alloc -> core on one stream (reset / dense skip alloc).
 template <int MODE>
 void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
 {
     kp.e0 = e0;
     const dim3 sblock((unsigned)(((kp.S * GRP) + WAVE - 1) / WAVE * WAVE));   // one thread per slot
-    const dim3 rblock((unsigned)h->nt);                                       // two threads per UE
-    const long long n_ue = (long long)n_env * kp.U;
+    const dim3 cblock((unsigned)h->nt);
     hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;       // diagnostic per-kernel timing
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL((ranenv_stream_kernel<MODE>), dim3(n_env), rblock, 0, stream, kp);
+    if (h->quads) {
+        if (kp.R <= 256) hipLaunchKernelGGL((ranenv_core_kernel<MODE, true, true>), dim3(n_env), cblock, 0, stream, kp);
+        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, true>), dim3(n_env), cblock, 0, stream, kp);
+    } else {
+        hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, false>), dim3(n_env), cblock, 0, stream, kp);
+    }
     if (ev) (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL((ranenv_ue_kernel<MODE>), dim3((unsigned)((n_ue + 255) / 256)), dim3(256), 0, stream, kp, n_env);
-    if (ev) (void)hipEventRecord(ev[3], stream);
-    if (MODE == MODE_RESET) hipLaunchKernelGGL((ranenv_obs_kernel<MODE_RESET>), dim3(n_env), sblock, 0, stream, kp);
-    else hipLaunchKernelGGL((ranenv_obs_kernel<MODE_STEP>), dim3(n_env), sblock, 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[4], stream);
 }
 
 // Fork the caller's stream into the chunk streams and join them back.
@@ -1181,8 +1307,13 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
-    h->nt = (2 * U + WAVE - 1) / WAVE * WAVE;   // stream kernel: two lanes per UE
-    if (h->nt > 256) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build streams at most 128 UEs per env"); }
+    {   // core workgroup: one lane per UE (or 8 lanes per UE quad with RANENV_QUADS=1), >= 16 slice lanes
+        const char *env_q = getenv("RANENV_QUADS");
+        h->quads = env_q && atoi(env_q) != 0;
+        const int need = h->quads ? (((U + 3) / 4) * 8 > U ? ((U + 3) / 4) * 8 : U) : U;
+        h->nt = (need + WAVE - 1) / WAVE * WAVE;
+        if (h->nt > ALLOC_NT) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build steps at most 128 UEs per env"); }
+    }
     h->lds_bytes = GRP * 4 * GRP * 8 + 3 * GRP * 8;   // static LDS of the widest kernel (obs)
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
@@ -1441,8 +1572,8 @@ int ranenv_step_profiled(ranenv_handle h, float *ms3, void *stream_)
     launch_chunk<MODE_STEP>(h, kp, 0, kp.B, stream);
     h->prof_on = false;
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventSynchronize(h->prof_ev[4]));
-    for (int k = 0; k < 4; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
+    HIP_TRY(h, hipEventSynchronize(h->prof_ev[2]));
+    for (int k = 0; k < 2; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
     return RANENV_OK;
 }
 

@@ -15,7 +15,7 @@ def per_kernel(d, counter):
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            if "ranenv_" in kn and r["Counter_Name"] == counter and "<2" not in kn:
+            if "ranenv_" in kn and r["Counter_Name"] == counter and "<2," not in kn:
                 agg[kn.split("ranenv_")[1].split("(")[0]].append(float(r["Counter_Value"]))
     return {k: sum(v[2:]) / len(v[2:]) for k, v in agg.items() if len(v) > 2}
 
