@@ -572,6 +572,111 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// SE row reduction through LDS: groups of 8 RBs (8*U floats, contiguous in an RB-major tile) are
+// copied global -> LDS by 16-byte-per-lane loads that bypass the VGPRs (global_load_lds_dwordx4,
+// "LDS-DMA"); lane u then reads its 8 values of the group from LDS (consecutive UEs = consecutive
+// banks) and feeds numpy's 8 accumulators.  A ring of LDS_NB group buffers keeps LDS_NB-1 groups in
+// flight per workgroup without holding a single register; one raw s_barrier per group, the refill
+// of a buffer is issued one group after its last read.  Measured: 5.6-5.7 TB/s against 2.6 TB/s for
+// one dword per lane and RB (tools/bw_probe.hip).  Needs 16-byte aligned tiles; otherwise the
+// dword stream (SeStream) is used.
+// ---------------------------------------------------------------------------------------------
+#ifndef RANENV_LDS_NB
+#define RANENV_LDS_NB 4
+#endif
+constexpr int LDS_NB = RANENV_LDS_NB;
+
+template <typename InFn>
+DEVFN void row_sums_lds(unsigned char *ring, const float *tile, int U, int R, int u, InFn in, double &full, double &part)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int span = (int)blockDim.x * 16;         // bytes one instruction of the whole workgroup copies
+    const int CB = 32 * U;                         // bytes of one 8-RB group
+    const int tail = R & 7, G = R >> 3, NG = G + (tail ? 1 : 0);
+    const int ni = (CB + span - 1) / span;         // instructions per group (workgroup-uniform)
+    int niw = 0;                                   // ... of which this wave really issues (wave-uniform)
+    for (int k = 0; k < ni; k++) niw += (k * span + wave * 1024 < CB) ? 1 : 0;
+    auto issue = [&](int g) {
+        const int bytes = g < G ? CB : tail * 4 * U;
+        const char *src = (const char *)tile + (size_t)g * CB;
+        unsigned char *dst = ring + (g % LDS_NB) * CB;
+        for (int k = 0; k < ni; k++) {
+            const int wbase = k * span + wave * 1024;
+            if (wbase < CB) {                      // same test as niw (wave-uniform)
+                const int off = wbase + lane * 16;
+                if (off < bytes)                   // lanes past the chunk neither read nor write
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                     (__attribute__((address_space(3))) void *)(dst + wbase), 16, 0, 0);
+            }
+        }
+    };
+    auto wait_group = [&](bool steady) {
+        // all but the (LDS_NB-2) youngest groups of this wave have landed
+        if (!steady || niw == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (niw == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LDS_NB - 2) * 1) : "memory");
+        else if (niw == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LDS_NB - 2) * 2) : "memory");
+        else if (niw == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LDS_NB - 2) * 3) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    for (int g = 0; g < LDS_NB - 1; g++) if (g < NG) issue(g);
+
+    const RowPlan pl = make_row_plan(R);
+    double f[8], g8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { f[j] = 0.0; g8[j] = 0.0; }
+    double fr = 0.0, gr = 0.0, lf = 0.0, lg = 0.0, rf = 0.0, rg = 0.0;
+    int leaf = 0, left_in_leaf = pl.len0 >> 3;            // workgroup-uniform cursor
+    auto fold = [&](int k) {
+        const bool left = pl.lsplit ? (k < 2) : (k < 1);
+        const bool first = pl.lsplit ? (k == 0 || k == 2) : (k <= 1);
+        if (left) { if (first) { lf = fr; lg = gr; } else { lf = lf + fr; lg = lg + gr; } }
+        else      { if (first) { rf = fr; rg = gr; } else { rf = rf + fr; rg = rg + gr; } }
+    };
+    for (int g = 0; g < NG; g++) {
+        wait_group(g + LDS_NB - 1 <= G);          // counted wait only while every younger group is a full one
+        __builtin_amdgcn_s_barrier();
+        if (g + LDS_NB - 1 < NG) issue(g + LDS_NB - 1);
+        const float *b = (const float *)(ring + (g % LDS_NB) * CB) + u;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = (g < G || j < tail) ? b[j * U] : 0.0f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before anyone refills this buffer
+        const int r0 = g * 8;
+        if (g < G) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float xs = in(r0 + j) ? x[j] : 0.0f;
+                f[j] += (double)x[j];
+                g8[j] += (double)xs;
+            }
+            if (--left_in_leaf == 0) {
+                fr = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                gr = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
+#pragma unroll
+                for (int j = 0; j < 8; j++) { f[j] = 0.0; g8[j] = 0.0; }
+                if (!(leaf == pl.n_leaves - 1 && tail > 0)) fold(leaf);
+                leaf += 1;
+                left_in_leaf = ((leaf == 1) * pl.len1 + (leaf == 2) * pl.len2 + (leaf == 3) * pl.len3) >> 3;
+            }
+        } else {
+            if (G == 0) { fr = 0.0; gr = 0.0; }              // n < 8: numpy's plain loop from 0.0
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                if (j < tail) {
+                    const float xs = in(r0 + j) ? x[j] : 0.0f;
+                    fr += (double)x[j];
+                    gr += (double)xs;
+                }
+            }
+            fold(pl.n_leaves - 1);
+        }
+    }
+    __builtin_amdgcn_s_barrier();     // the ring is free again (the caller may reuse LDS)
+    if (pl.n_leaves == 1) { full = lf; part = lg; return; }
+    full = lf + rf; part = lg + rg;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SE row reduction, 16 B per lane: lane (c, j) of an env loads, for every group of 8 RBs, the float4
 // of RB 8g + j and UEs 4c..4c+3.  Lane j therefore IS numpy's accumulator j for those four UEs, and
 // the leaf result ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is an xor-butterfly over the 8 lanes of a quad.
@@ -707,10 +812,13 @@ struct SharedCore {
     int cnt[GRP][GRP];                             // RBs of each slot
 };
 
-template <int MODE, bool SMALL, bool QUADS>
+// STREAM: 0 = lane = UE, one dword per RB; 1 = float4 quads; 2 = LDS-DMA staging (default when aligned)
+template <int MODE, bool SMALL, int STREAM>
 __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 {
+    constexpr bool QUADS = STREAM == 1;
     __shared__ SharedCore sh;
+    extern __shared__ __align__(16) unsigned char dyn_ring[];
     auto &rows = sh.rows; auto &xr = sh.xr;
     const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
@@ -756,7 +864,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
                 if (uq < U) { ust[k] = (unsigned)p.st.rb_start[(size_t)e * U + uq]; ucn[k] = (unsigned)p.st.rb_count[(size_t)e * U + uq]; }
             }
         }
-    } else {
+    } else if (STREAM == 0) {
         se1.init(tile, U, tid < U ? tid : U - 1, R);   // lane = UE: one dword per RB
     }
 
@@ -805,6 +913,17 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
         __syncthreads();
         my_full = sh.se_full[u]; my_part = sh.se_part[u];
+    } else if (STREAM == 2) {
+        unsigned char *ring = (unsigned char *)(((size_t)dyn_ring + 15) & ~(size_t)15);
+        if (MODE == MODE_STEP) {
+            const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
+            row_sums_lds(ring, tile, U, R, u, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part);
+        } else if (MODE == MODE_DENSE) {
+            const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
+            row_sums_lds(ring, tile, U, R, u, [=](int r) { return mrow[r] != 0; }, my_full, my_part);
+        } else {
+            row_sums_lds(ring, tile, U, R, u, [](int) { return false; }, my_full, my_part);
+        }
     } else {
         if (MODE == MODE_STEP) {
             const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
@@ -1096,7 +1215,8 @@ struct ranenv {
     Cached cache[6];
     int cache_next = 0;
     bool use_graph = true;
-    bool quads = false;                 // core variant: float4 quads (true) or lane = UE dword stream
+    bool quads = false;                 // core variant: float4 quads (RANENV_QUADS=1)
+    bool lds_dma = false;               // core variant: LDS-DMA staged SE stream (RANENV_LDS_DMA=1 enables)
     bool prof_on = false;               // ranenv_step_profiled: events around each kernel
     hipEvent_t prof_ev[3] = {};
     std::string err;
@@ -1148,11 +1268,18 @@ void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[1], stream);
+    // LDS-DMA needs 16-byte aligned tiles: pool base, tile stride and (for explicit tiles) U*R*4
+    const float *tiles = kp.se_tiles ? kp.se_tiles : kp.se_pool;
+    const long long tstride = kp.se_tiles ? (long long)kp.U * kp.R : kp.se_stride;
+    const bool aligned = (((size_t)tiles) & 15) == 0 && (tstride & 3) == 0;
     if (h->quads) {
-        if (kp.R <= 256) hipLaunchKernelGGL((ranenv_core_kernel<MODE, true, true>), dim3(n_env), cblock, 0, stream, kp);
-        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, true>), dim3(n_env), cblock, 0, stream, kp);
+        if (kp.R <= 256) hipLaunchKernelGGL((ranenv_core_kernel<MODE, true, 1>), dim3(n_env), cblock, 0, stream, kp);
+        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 1>), dim3(n_env), cblock, 0, stream, kp);
+    } else if (h->lds_dma && aligned) {
+        const size_t ring = (size_t)LDS_NB * 32 * kp.U + 16;
+        hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 2>), dim3(n_env), cblock, ring, stream, kp);
     } else {
-        hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, false>), dim3(n_env), cblock, 0, stream, kp);
+        hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 0>), dim3(n_env), cblock, 0, stream, kp);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
 }
@@ -1310,6 +1437,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     {   // core workgroup: one lane per UE (or 8 lanes per UE quad with RANENV_QUADS=1), >= 16 slice lanes
         const char *env_q = getenv("RANENV_QUADS");
         h->quads = env_q && atoi(env_q) != 0;
+        const char *env_l = getenv("RANENV_LDS_DMA");
+        h->lds_dma = env_l && atoi(env_l) != 0;   // opt-in: measured slower when fused (its in-flight data competes for LDS)
         const int need = h->quads ? (((U + 3) / 4) * 8 > U ? ((U + 3) / 4) * 8 : U) : U;
         h->nt = (need + WAVE - 1) / WAVE * WAVE;
         if (h->nt > ALLOC_NT) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build steps at most 128 UEs per env"); }

@@ -356,7 +356,7 @@ def generate_scaled_scenarios(
     for i in range(n_scenarios):
         n_act = int(rng.integers(min_slices, n_slices, endpoint=True))
         slices = rng.choice(n_slices, n_act, replace=False)
-        types = rng.choice(len(SLICE_TEMPLATES), n_act, replace=False)
+        types = rng.choice(len(SLICE_TEMPLATES), n_act, replace=n_act > len(SLICE_TEMPLATES))
         counts = rng.integers(min_ues, max_ues_slice, n_act, endpoint=True)
         while counts.sum() > n_ues:
             counts[np.argmax(counts)] -= 1

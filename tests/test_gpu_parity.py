@@ -190,3 +190,54 @@ def test_batch_vs_oracle(policy, intra, size):
                 oenvs[b].reset(se_pool[tile_of(b, t + 1)])
                 np.testing.assert_allclose(after[b], oenvs[b].obs()["obs_inter"], rtol=0, atol=OBS_TOL)
     env.close()
+
+
+@pytest.mark.parametrize("shape", [
+    dict(S=3, U=7, R=5, G=1, Us=4),        # R < 8: numpy's plain loop, single wave
+    dict(S=4, U=37, R=100, G=5, Us=12),    # one leaf with a tail, U not a multiple of 4
+    dict(S=16, U=128, R=300, G=3, Us=16),  # three leaves (150 -> 72+78 | 150), full slot grid
+    dict(S=6, U=64, R=408, G=8, Us=11),    # four leaves, G does not divide R
+])
+@pytest.mark.parametrize("variant", ["default", "quads", "lds"])
+def test_shapes_vs_oracle(shape, variant, monkeypatch):
+    """Other sizes than the BASELINE ones: every numpy pairwise-sum shape of the SE row reduction,
+    partial quads, a full 16 x 16 slot grid; for each of the three SE-stream variants."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    from oracle import pyoracle
+    monkeypatch.setenv("RANENV_QUADS", "1" if variant == "quads" else "0")
+    monkeypatch.setenv("RANENV_LDS_DMA", "1" if variant == "lds" else "0")
+    S, U, R, G, Us = (shape[k] for k in ("S", "U", "R", "G", "Us"))
+    tabs = generate_scaled_scenarios(3, seed=5, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=max(1, S // 2),
+                                     min_ues=max(1, Us // 3))
+    B, steps = 6, 14
+    rng = np.random.default_rng(7)
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    se_pool = np.stack([se_tile(90, t, U, R) for t in range(B * steps)])
+    env = _env(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+               n_scenarios=tabs.n_scenarios, max_steps=steps)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(_rb_major(se_pool), device=env.device))
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
+    env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
+    env.set_policy(0, 255)
+    ocfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+    oenvs = []
+    for b in range(B):
+        o = pyoracle.OracleEnv(ocfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
+    env.reset()
+    for t in range(steps):
+        sc = rng.uniform(-1, 1, (B, S)); ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+        obs, rew, done = env.step(sc, ic)
+        g = {k: x.cpu().numpy() for k, x in env.views().items()}
+        for b, o in enumerate(oenvs):
+            o.step(sc[b], ic[b], se_pool[b * steps + t], trf[b * steps + t])
+            raw = o.raw()
+            for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (shape, variant, t, b, name)
+            oo = o.obs()
+            np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(obs["obs_intra"][b].cpu().numpy(), oo["obs_intra"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=REW_TOL)
+    env.close()

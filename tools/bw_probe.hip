@@ -66,6 +66,46 @@ __global__ void __launch_bounds__(256) kC(const float4 *pool, const int *tile_of
     if (acc == 12345.f) out[blockIdx.x] = acc;
 }
 
+
+// D: LDS-DMA staging: groups of 8 rows (8*U floats, contiguous) are copied global -> LDS with 16-byte
+// per-lane loads that bypass the VGPRs (global_load_lds_dwordx4); lane = UE then reads its 8 values of
+// the group from LDS.  NB ring buffers, one barrier per group, refill lags one group.
+template <int NB, int NI>
+__global__ void __launch_bounds__(128) kD(const float *pool, const int *tile_of, float *out, int U, int R)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    const float *tile = pool + (size_t)tile_of[blockIdx.x] * U * R;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int u = tid < U ? tid : U - 1;
+    const int CB = 32 * U;                    // bytes per 8-row group
+    const int G = R / 8;
+    auto issue = [&](int g) {
+        const char *src = (const char *)tile + (size_t)g * CB;
+        unsigned char *dst = lds + (g % NB) * CB;
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const int off = k * 2048 + wave * 1024 + lane * 16;
+            if (off < CB)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(dst + k * 2048 + wave * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < NB - 1; g++) if (g < G) issue(g);
+    float acc = 0.f;
+    for (int g = 0; g < G; g++) {
+        if (g + NB - 1 <= G) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + NB - 1 < G) issue(g + NB - 1);
+        const float *b = (const float *)(lds + (g % NB) * CB);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += b[j * U + u];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (tid < U) out[(size_t)blockIdx.x * U + u] = acc;
+}
+
 int main()
 {
     const int U = 100, R = 135, B = 4096, T = 40000;
@@ -92,6 +132,12 @@ int main()
     run("B dwordx4 quad x row8 d2", [&] { hipLaunchKernelGGL(kB<2>, dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
     run("B dwordx4 quad x row8 d4", [&] { hipLaunchKernelGGL(kB<4>, dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
     run("B dwordx4 quad x row8 d8", [&] { hipLaunchKernelGGL(kB<8>, dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
+    hipFuncSetAttribute((const void *)kD<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)kD<6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)kD<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    run("D lds-dma ring 3", [&] { hipLaunchKernelGGL((kD<3, 2>), dim3(B), dim3(128), 3 * 32 * U, 0, pool, tile_of, out, U, R); });
+    run("D lds-dma ring 4", [&] { hipLaunchKernelGGL((kD<4, 2>), dim3(B), dim3(128), 4 * 32 * U, 0, pool, tile_of, out, U, R); });
+    run("D lds-dma ring 6", [&] { hipLaunchKernelGGL((kD<6, 2>), dim3(B), dim3(128), 6 * 32 * U, 0, pool, tile_of, out, U, R); });
     run("C flat float4", [&] { hipLaunchKernelGGL(kC, dim3(B), dim3(256), 0, 0, (const float4 *)pool, tile_of, out, U * R / 4); });
     return 0;
 }
