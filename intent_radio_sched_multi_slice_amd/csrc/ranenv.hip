@@ -151,8 +151,9 @@ constexpr int GRP = 16;   // lanes per (env) group in alloc1/obs and per (env, s
 // ---------------------------------------------------------------------------------------------
 // Lane u reduces row u of an RB-major tile (element r at byte offset r*U*4 + u*4).  Loads go through
 // a wave-uniform buffer descriptor: the row offset is a scalar, the lane offset one VGPR, so a load
-// costs no vector address arithmetic.  Three groups of 8 loads rotate through named registers
-// (qa/qb/qc, no moves), i.e. 16-24 loads per lane stay in flight while a group is being summed.
+// costs no vector address arithmetic.  SE_NQ groups of 8 loads rotate through fixed registers (no
+// moves), i.e. up to 8*SE_NQ loads per lane are in flight: the per-workgroup time is a chain of memory
+// round trips (~1.8 us each under load), and the row costs ceil(R / (8*SE_NQ)) of them.
 //
 // Summation order = numpy's pairwise_sum (see np_sum_lds): the row is cut into leaves of <= 128
 // RBs by halving at multiples of 8; inside a leaf, accumulator j takes the elements j mod 8, the
@@ -181,8 +182,16 @@ DEVFN RowPlan make_row_plan(int n)
     return pl;
 }
 
+#ifndef RANENV_SE_DEPTH
+#define RANENV_SE_DEPTH 3
+#endif
+#ifndef RANENV_LATE_STATE
+#define RANENV_LATE_STATE 0
+#endif
+constexpr int SE_NQ = RANENV_SE_DEPTH;   // 8-row groups in flight per lane
+
 struct SeStream {
-    float qa[8], qb[8], qc[8];
+    float q[SE_NQ][8];
     __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
     int voff, row_bytes, r_last;
 
@@ -199,9 +208,8 @@ struct SeStream {
     {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
         voff = u * 4; row_bytes = U * 4; r_last = R - 1;
-        load(qa, 0);
-        if (R > 8) load(qb, 8);
-        if (R > 16) load(qc, 16);
+#pragma unroll
+        for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
 };
 
@@ -210,8 +218,10 @@ struct SeStream {
 // exactly, so the result is numpy's bit for bit while the loop body stays branch-free; the only
 // control flow per 8-group is one wave-uniform "leaf finished?" test.  Only the row's last leaf can
 // have a tail (R mod 8 elements); it is added sequentially after the loop, as numpy does.
-template <typename InFn>
-DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
+// late() is called once, before the last pass over the queue: what it loads lands under the last
+// round trip of the stream, in registers the drained part of the queue no longer needs.
+template <typename InFn, typename LateFn>
+DEVFN void row_sums(SeStream &st, int R, InFn in, LateFn late, double &full, double &part)
 {
     const RowPlan pl = make_row_plan(R);
     const int tail = R & 7, G = R >> 3;
@@ -257,25 +267,25 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
         }
         fold(pl.n_leaves - 1);
     };
+    auto pass = [&](int gi) {          // one turn of the queue: slot d holds group gi + d
+#pragma unroll
+        for (int d = 0; d < SE_NQ; d++) {
+            if (gi + d < G) {
+                consume(st.q[d], (gi + d) * 8);
+                if ((gi + d + SE_NQ) * 8 < R) st.load(st.q[d], (gi + d + SE_NQ) * 8);
+            }
+        }
+    };
+    if (G == 0) late();
 #pragma unroll 1
-    for (int gi = 0; gi < G; gi += 3) {
-        const int r0 = gi * 8;
-        consume(st.qa, r0);
-        if (r0 + 24 < R) st.load(st.qa, r0 + 24);
-        if (gi + 1 < G) {
-            consume(st.qb, r0 + 8);
-            if (r0 + 32 < R) st.load(st.qb, r0 + 32);
-        }
-        if (gi + 2 < G) {
-            consume(st.qc, r0 + 16);
-            if (r0 + 40 < R) st.load(st.qc, r0 + 40);
-        }
+    for (int gi = 0; gi < G; gi += SE_NQ) {
+        if (gi + SE_NQ >= G) late();       // wave-uniform: the last turn of the queue
+        pass(gi);
     }
     if (tail > 0) {
-        const int m3 = G % 3;
-        if (m3 == 0) add_tail(st.qa, G * 8);
-        else if (m3 == 1) add_tail(st.qb, G * 8);
-        else add_tail(st.qc, G * 8);
+        const int m = G % SE_NQ;
+#pragma unroll
+        for (int d = 0; d < SE_NQ; d++) if (m == d) add_tail(st.q[d], G * 8);
     }
     if (pl.n_leaves == 1) { full = lf; part = lg; return; }
     full = lf + rf; part = lg + rg;
@@ -373,10 +383,16 @@ DEVFN void row_sums2(SeStream2 &st, int R, int h, InFn in, double &full, double 
     full = lf + rf; part = lg + rg;
 }
 
+#if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of wave 0 / wave 1 at phase boundaries */
+#define RANENV_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (k) + 5 * (int)(threadIdx.x >> 6) < p.S) \
+    p.st.policy_scores[(size_t)(p.e0 + blockIdx.x) * p.S + (k) + 5 * (threadIdx.x >> 6)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define RANENV_STAMP(k) do { } while (0)
+#endif
 
 // =============================================================================================
-// Kernel 1/4  alloc: one workgroup = one env, thread = (slice s = tid / 16, UE slot = tid % 16).
+// Allocation (kernel 1/2, or the first phase of the fused step kernel): one workgroup = one env,
+// thread = (slice s = slot / 16, UE position = slot % 16).
 //   Policy  MARR agents/marr.py:40-47, MAPF agents/mapf.py:41-111
 //   Inter   IBSched.action_format agents/ib_sched.py:240-269, scores_to_rbs / round_int_equal_sum
 //           agents/common.py:442-505          (threads 0..15, one per slice)
@@ -385,34 +401,54 @@ DEVFN void row_sums2(SeStream2 &st, int R, int h, InFn in, double &full, double 
 // =============================================================================================
 constexpr int ALLOC_NT = GRP * GRP;   // 256
 
-__global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
-{
-    __shared__ double xs[4][GRP];            // cross-slice rows
-    __shared__ double rows[GRP][2][GRP];     // per-slice rows
-    __shared__ int sh_rbs[GRP], sh_off[GRP];
-    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
-    const int s = tid / GRP, pos = tid % GRP;          // intra role: (slice, UE slot)
-    const int S = p.S, U = p.U;
-    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
-    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
-    double *ra = rows[s][0], *rb = rows[s][1];
+struct SharedAlloc {
+    double xs[4][GRP];            // cross-slice rows
+    double rows[GRP + 1][2][GRP]; // per-slice rows (+ one row shared by slots past the grid: zeros only)
+    int rbs[GRP], off[GRP];
+};
 
-    // ---- this thread's UE: slot tid of the env's slot-ordered records (coalesced, one level) ------
+// The allocation of one env by the whole workgroup.  Slot k = (slice k / 16, UE position k % 16); the
+// S*16 slots are covered in NPASS passes of blockDim.x slots (blockDim.x a multiple of 64, so a slice's
+// 16 lanes never straddle a wave).  Lanes that exchange data through LDS always sit in one wave
+// (threads 0..15 for the inter-slice part, the 16 lanes of a slice for the intra-slice part), so an
+// LDS wait orders them; only the two hand-overs between the parts need a workgroup barrier.
+// Results go to rb_start / rb_count by UE in HBM and, when lds_start != nullptr, to those LDS arrays
+// too (the caller zeroes them and adds the barrier before reading).
+template <int NPASS>
+DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen, int *lds_start, int *lds_count)
+{
+    auto &xs = sa.xs; auto &rows = sa.rows;
+    auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    const int tid = threadIdx.x, nthr = (int)blockDim.x;
+    const int pos = tid % GRP;
+    const int S = p.S, U = p.U;
     const int NS16 = S * GRP;
-    const bool in_grid = tid < NS16;
-    int ue = -1, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
-    if (in_grid) {
-        const size_t ts = (size_t)sc * NS16 + tid, es = (size_t)e * NS16 + tid;
-        ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; pk = p.tab.slot_pk[ts];
-        q = p.st.slot_q[es]; wsent = p.st.slot_ws[es]; sem = p.st.slot_sem[es];
-    }
-    const bool have = ue >= 0;
     const int gsh = (tid & 63) & ~(GRP - 1);
-    const int n = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));   // UEs of this slice
-    const double occ = (double)q / (double)mp;
-    const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
     const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
-    if (mapf) { ra[pos] = have ? occ : 0.0; rb[pos] = have ? hm : 0.0; }
+
+    // ---- this thread's UEs: slot-ordered records (coalesced, one level) ---------------------------
+    int ue[NPASS], q[NPASS], mp[NPASS], pk[NPASS], nn[NPASS]; long long wsent[NPASS]; double sem[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+        const int slot = ps * nthr + tid;
+        ue[ps] = -1; q[ps] = 0; mp[ps] = 1; pk[ps] = 1; wsent[ps] = 0; sem[ps] = 0.0;
+        if (slot < NS16) {
+            const size_t ts = (size_t)sc * NS16 + slot, es = (size_t)e * NS16 + slot;
+            ue[ps] = p.tab.slot_ue[ts]; mp[ps] = p.tab.slot_mp[ts]; pk[ps] = p.tab.slot_pk[ts];
+            q[ps] = p.st.slot_q[es]; wsent[ps] = p.st.slot_ws[es]; sem[ps] = p.st.slot_sem[es];
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+        const int s = (ps * nthr + tid) / GRP;
+        const bool have = ue[ps] >= 0;
+        nn[ps] = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));   // UEs of this slice
+        if (mapf && s < GRP) {
+            const double occ = (double)q[ps] / (double)mp[ps];
+            const double hm = hlen > 0 ? (double)wsent[ps] / (double)hlen : 0.0;
+            rows[s][0][pos] = have ? occ : 0.0; rows[s][1][pos] = have ? hm : 0.0;
+        }
+    }
 
     // ---- inter role: thread t < 16 is slice t ---------------------------------------------------
     const int s1 = tid;
@@ -423,152 +459,176 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
         active = si[0]; nues1 = si[2]; bsize = si[3]; msg = si[5]; sorted = si[7];
     }
     __syncthreads();
-    double score = -1.0;
-    if (mapf) {
-        double occ_mb = 0.0, thr_mb = 0.0;
-        if (ok1 && active) {
-            const double pkt = (double)msg, bmax = (double)bsize;
-            occ_mb = ((np_sum16_lds(rows[s1][0], nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
-            thr_mb = ((np_sum16_lds(rows[s1][1], nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+    if (tid < WAVE) {            // wave 0; the other waves go straight to the barrier below
+        double score = -1.0;
+        if (mapf) {
+            double occ_mb = 0.0, thr_mb = 0.0;
+            if (ok1 && active) {
+                const double pkt = (double)msg, bmax = (double)bsize;
+                occ_mb = ((np_sum16_lds(rows[s1][0], nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
+                thr_mb = ((np_sum16_lds(rows[s1][1], nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+            }
+            if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
+            wave_sync();
+            double w = 0.0;
+            if (tid < GRP) {
+                double mx = xs[0][0];
+#pragma unroll
+                for (int j = 1; j < 16; j++) { const double v = xs[0][j]; mx = (j < S && v > mx) ? v : mx; }
+                w = d_isclose(thr_mb, 0.0) ? 2.0 * mx : occ_mb / thr_mb;                            // :91-100
+                if (!active) w = 0.0;
+                xs[2][s1] = ok1 ? w : 0.0;
+            }
+            wave_sync();
+            if (tid < GRP) {
+                const double ws = np_sum16_lds(xs[2], S);
+                score = (ws > 0.0 ? w / ws : 2.0) - 1.0;                                            // :105-109
+            }
+            wave_sync();
+        } else if (ok1) {
+            score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);
         }
-        if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
-        __syncthreads();
-        double w = 0.0;
+        if (ok1) p.st.policy_scores[(size_t)e * S + s1] = score;
+        if (tid < GRP) xs[3][s1] = score;
+        wave_sync();
+        const int T = p.R / p.G;
+        double my_a = -1.0;
         if (tid < GRP) {
-            double mx = xs[0][0];
-#pragma unroll
-            for (int j = 1; j < 16; j++) { const double v = xs[0][j]; mx = (j < S && v > mx) ? v : mx; }
-            w = d_isclose(thr_mb, 0.0) ? 2.0 * mx : occ_mb / thr_mb;                            // :91-100
-            if (!active) w = 0.0;
-            xs[2][s1] = ok1 ? w : 0.0;
+            my_a = (ok1 && active) ? xs[3][sorted] : -1.0;                                           // ib_sched.py:247-255
+            xs[0][s1] = ok1 ? my_a + 1.0 : 0.0;
+            xs[1][s1] = ok1 ? (double)active : 0.0;
         }
-        __syncthreads();
+        wave_sync();
+        double my_v = 0.0; bool nzf = false; int m_nz = 0, slot = 0;
         if (tid < GRP) {
-            const double ws = np_sum16_lds(xs[2], S);
-            score = (ws > 0.0 ? w / ws : 2.0) - 1.0;                                            // :105-109
+            const double ssum = np_sum16_lds(xs[0], S), asum = np_sum16_lds(xs[1], S);
+            if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
+            nzf = my_v != 0.0;
+            // compaction of the non-zero values in slice order (common.py:484-485)
+            const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull);
+            m_nz = __popc(gm); slot = __popc(gm & ((1u << s1) - 1u));
+            xs[2][s1] = 0.0;
         }
-        __syncthreads();
-    } else if (ok1) {
-        score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);
-    }
-    if (ok1) p.st.policy_scores[(size_t)e * S + s1] = score;
-    if (tid < GRP) xs[3][s1] = score;
-    __syncthreads();
-    const int T = p.R / p.G;
-    double my_a = -1.0;
-    if (tid < GRP) {
-        my_a = (ok1 && active) ? xs[3][sorted] : -1.0;                                           // ib_sched.py:247-255
-        xs[0][s1] = ok1 ? my_a + 1.0 : 0.0;
-        xs[1][s1] = ok1 ? (double)active : 0.0;
-    }
-    __syncthreads();
-    double my_v = 0.0; bool nzf = false; int m_nz = 0, slot = 0;
-    if (tid < GRP) {
-        const double ssum = np_sum16_lds(xs[0], S), asum = np_sum16_lds(xs[1], S);
-        if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
-        nzf = my_v != 0.0;
-        // compaction of the non-zero values in slice order (common.py:484-485)
-        const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull);
-        m_nz = __popc(gm); slot = __popc(gm & ((1u << s1) - 1u));
-        xs[2][s1] = 0.0;
-    }
-    __syncthreads();
-    if (tid < GRP) { if (nzf) xs[2][slot] = my_v; xs[3][s1] = my_v; }
-    __syncthreads();
-    if (tid < GRP) {
-        const double tot = np_sum16_lds(xs[2], m_nz);
-        const int my_prop = nzf ? (int)((double)T * my_v / tot) : 0;                  // :488-490 (value >= 0)
-        int acc = my_prop;
+        wave_sync();
+        if (tid < GRP) { if (nzf) xs[2][slot] = my_v; xs[3][s1] = my_v; }
+        wave_sync();
+        if (tid < GRP) {
+            const double tot = np_sum16_lds(xs[2], m_nz);
+            const int my_prop = nzf ? (int)((double)T * my_v / tot) : 0;                  // :488-490 (value >= 0)
+            int acc = my_prop;
 #pragma unroll
-        for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
-        const int adj = T - acc;                                                     // :493-499
-        int extra = 0;
-        if (nzf && adj > 0) {
-            int rank = 0;
+            for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+            const int adj = T - acc;                                                     // :493-499
+            int extra = 0;
+            if (nzf && adj > 0) {
+                int rank = 0;
 #pragma unroll
-            for (int j = 0; j < 16; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
-            extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
+                for (int j = 0; j < 16; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
+                extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
+            }
+            const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (s1 >= d) ? v : 0; }
+            sa.rbs[s1] = mine; sa.off[s1] = incl - mine;
         }
-        const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (s1 >= d) ? v : 0; }
-        sh_rbs[s1] = mine; sh_off[s1] = incl - mine;
     }
     __syncthreads();
 
     // ---- intra-slice: 16 lanes per slice ---------------------------------------------------------
-    const int n_rbs = s < S ? sh_rbs[s] : 0, off = s < S ? sh_off[s] : 0;
-    int choice = p.fixed_intra;
-    if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && s < S) ? (int)p.intra[(size_t)e * S + s] : RANENV_INTRA_RR;
-    const bool has_pkts = have && !d_isclose(occ, 0.0);
-    double avail = 0.0;                          // PF / MT path, evaluated by every slice
-    if (have) {
-        const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // :573-578
-        const double cap = sem * slice_bw / (double)n;
-        const double backlog = occ * (double)mp * (double)pk;
-        avail = cap < backlog ? cap : backlog;
-    }
-    ra[pos] = avail;
-    __syncthreads();
-    double num = avail;                                                            // MT: weights = avail
-    if (choice == RANENV_INTRA_PF) {                                               // :584-602
-        double max_avail = ra[0];
 #pragma unroll
-        for (int k = 1; k < 16; k++) { const double av = ra[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
-        double snt = hm * (double)pk;
-        if (d_isclose(avail, 0.0)) snt = 1.0;
-        num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
-    }
-    rb[pos] = have ? num : 0.0;
-    __syncthreads();
-    const double wsum = np_sum16_lds(rb, n);
-    const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
-    const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
-    const bool nzv = my_val != 0.0;
-    const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
-    const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
-    __syncthreads();
-    ra[pos] = 0.0;
-    __syncthreads();
-    if (nzv) ra[slot_v] = my_val;                                                  // compaction (:484-485)
-    rb[pos] = my_val;
-    __syncthreads();
-    int count = 0;
-    if (use_round) {
-        const double tot = np_sum16_lds(ra, m_v);
-        const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
-        int acc = prop;
-#pragma unroll
-        for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
-        const int adj = n_rbs - acc;
-        count = prop;
-        if (nzv && adj > 0) {
-            int rank = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) { const double xk = rb[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
-            count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
+    for (int ps = 0; ps < NPASS; ps++) {
+        const int slot_g = ps * nthr + tid;
+        const int s = slot_g / GRP;
+        const int sr = s < GRP ? s : GRP;          // slots past the grid share the spare row (zeros only)
+        double *ra = rows[sr][0], *rb = rows[sr][1];
+        const bool have = ue[ps] >= 0;
+        const int n = nn[ps];
+        const int n_rbs = s < S ? sa.rbs[s] : 0, off = s < S ? sa.off[s] : 0;
+        int choice = p.fixed_intra;
+        if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && s < S) ? (int)p.intra[(size_t)e * S + s] : RANENV_INTRA_RR;
+        const double occ = (double)q[ps] / (double)mp[ps];
+        const double hm = hlen > 0 ? (double)wsent[ps] / (double)hlen : 0.0;
+        const bool has_pkts = have && !d_isclose(occ, 0.0);
+        double avail = 0.0;                          // PF / MT path, evaluated by every slice
+        if (have) {
+            const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // :573-578
+            const double cap = sem[ps] * slice_bw / (double)n;
+            const double backlog = occ * (double)mp[ps] * (double)pk[ps];
+            avail = cap < backlog ? cap : backlog;
         }
-    } else {
-        // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
-        const bool account = choice == RANENV_INTRA_RR;
-        const unsigned gmr = (unsigned)((__ballot(has_pkts && account) >> gsh) & 0xffffull);
-        int k_sel = __popc(gmr), idx = __popc(gmr & ((1u << pos) - 1u));
-        const bool all = (k_sel == 0);
-        if (all) { k_sel = n; idx = pos; }
-        if (have && (all || has_pkts) && k_sel > 0) {
-            const unsigned each = (unsigned)n_rbs / (unsigned)k_sel, rem = (unsigned)n_rbs - each * (unsigned)k_sel;
-            count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
-        }
-    }
-    int incl = count;                                                              // :464-478 contiguous ranges
+        ra[pos] = avail;
+        wave_sync();
+        double num = avail;                                                            // MT: weights = avail
+        if (choice == RANENV_INTRA_PF) {                                               // :584-602
+            double max_avail = ra[0];
 #pragma unroll
-    for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (pos >= d) ? v : 0; }
-    if (have) {
-        p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
-        p.st.rb_count[(size_t)e * U + ue] = count;
+            for (int k = 1; k < 16; k++) { const double av = ra[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+            double snt = hm * (double)pk[ps];
+            if (d_isclose(avail, 0.0)) snt = 1.0;
+            num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
+        }
+        wave_sync();
+        rb[pos] = have ? num : 0.0;
+        wave_sync();
+        const double wsum = np_sum16_lds(rb, n);
+        const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
+        const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
+        const bool nzv = my_val != 0.0;
+        const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
+        const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
+        wave_sync();
+        ra[pos] = 0.0;
+        wave_sync();
+        if (nzv) ra[slot_v] = my_val;                                                  // compaction (:484-485)
+        rb[pos] = my_val;
+        wave_sync();
+        int count = 0;
+        if (use_round) {
+            const double tot = np_sum16_lds(ra, m_v);
+            const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
+            int acc = prop;
+#pragma unroll
+            for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+            const int adj = n_rbs - acc;
+            count = prop;
+            if (nzv && adj > 0) {
+                int rank = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const double xk = rb[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+                count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
+            }
+        } else {
+            // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
+            const bool account = choice == RANENV_INTRA_RR;
+            const unsigned gmr = (unsigned)((__ballot(has_pkts && account) >> gsh) & 0xffffull);
+            int k_sel = __popc(gmr), idx = __popc(gmr & ((1u << pos) - 1u));
+            const bool all = (k_sel == 0);
+            if (all) { k_sel = n; idx = pos; }
+            if (have && (all || has_pkts) && k_sel > 0) {
+                const unsigned each = (unsigned)n_rbs / (unsigned)k_sel, rem = (unsigned)n_rbs - each * (unsigned)k_sel;
+                count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
+            }
+        }
+        int incl = count;                                                              // :464-478 contiguous ranges
+#pragma unroll
+        for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (pos >= d) ? v : 0; }
+        if (have) {
+            p.st.rb_start[(size_t)e * U + ue[ps]] = off + incl - count;
+            p.st.rb_count[(size_t)e * U + ue[ps]] = count;
+            if (lds_start) { lds_start[ue[ps]] = off + incl - count; lds_count[ue[ps]] = count; }
+        }
+        wave_sync();      // this pass's rows are read out before a later pass of the same wave reuses a row
     }
-    if (in_grid) p.st.slot_rbc[(size_t)e * NS16 + tid] = count;
+}
+
+__global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
+{
+    __shared__ SharedAlloc sa;
+    const int e = p.e0 + blockIdx.x;
+    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
+    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
+    alloc_phase<1>(p, sa, e, sc, hlen, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -813,10 +873,13 @@ struct SharedCore {
 };
 
 // STREAM: 0 = lane = UE, one dword per RB; 1 = float4 quads; 2 = LDS-DMA staging (default when aligned)
-template <int MODE, bool SMALL, int STREAM>
+// FUSE: 0 = the allocation was made by ranenv_alloc_kernel; 1 / 2 = this kernel makes it first, in that
+//       many passes of blockDim.x slots (MODE_STEP with STREAM 0 only)
+template <int MODE, bool SMALL, int STREAM, int FUSE = 0>
 __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 {
     constexpr bool QUADS = STREAM == 1;
+    static_assert(FUSE == 0 || (MODE == MODE_STEP && STREAM == 0), "fused allocation: step mode, dword stream");
     __shared__ SharedCore sh;
     extern __shared__ __align__(16) unsigned char dyn_ring[];
     auto &rows = sh.rows; auto &xr = sh.xr;
@@ -831,6 +894,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
     };
+    RANENV_STAMP(0);
     ranenv_episode ep = p.episodes[e];
     ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
     ep.se_len = uni(ep.se_len); ep.trf_len = uni(ep.trf_len);
@@ -868,33 +932,54 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         se1.init(tile, U, tid < U ? tid : U - 1, R);   // lane = UE: one dword per RB
     }
 
-    // ---- (2) UE role: everything this UE needs, issued now so that it lands under the stream -----
+    // ---- (0) fused allocation: the SE loads above are in flight while the RBs are handed out ----
+    if constexpr (FUSE > 0) {
+        __shared__ SharedAlloc sa;
+        int *a_start = &sh.cnt[0][0], *a_count = reinterpret_cast<int *>(&sh.se_full[0]);   // free until (2)
+        for (int i = tid; i < ALLOC_NT; i += (int)blockDim.x) { a_start[i] = 0; a_count[i] = 0; }
+        alloc_phase<FUSE>(p, sa, e, sc, hlen, a_start, a_count);
+        __syncthreads();
+    }
+
+    // ---- (2) UE role: only the RB range is needed by the stream; the rest of the UE's state is loaded
+    //      after it, so that the stream (24 loads + 16 double accumulators per lane) runs in few enough
+    //      registers for more workgroups per CU
     const bool act = tid < U;
     const int u = act ? tid : U - 1;
     const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
-    const int slc = p.tab.ue_slice[tu], ue_pos = p.tab.ue_pos[tu];
-    const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
-    int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
-    long long sum_age = 0, win_sent = 0, win_drop = 0;
-    if (MODE != MODE_RESET) {
-        total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
-        front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
+    int rb_start = 0, rb_count = 0;
+    if (MODE == MODE_STEP) {
+        if (FUSE > 0) { rb_start = sh.cnt[0][u]; rb_count = reinterpret_cast<const int *>(&sh.se_full[0])[u]; __syncthreads(); }
+        else { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
     }
-    if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
-    if (MODE == MODE_STEP) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
+    // the rest of the UE's state: requested by load_state(), which the stream calls before its last turn
+    int slc = -1, ue_pos = 0, pkt_size = 1, max_pkts = 1, max_age = 0;
+    int total = 0, front = 0, front_rem = 0, fifo = 0;
+    long long sum_age = 0, win_sent = 0, win_drop = 0;
     int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
     int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
-    if (hlen == D) { old_s = *rs; old_d = *rd; }
     double traffic = 0.0;
-    if (MODE != MODE_RESET)
-        traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
-    const double occ_prev = (double)total / (double)max_pkts;
+    auto load_state = [&]() {
+        slc = p.tab.ue_slice[tu]; ue_pos = p.tab.ue_pos[tu];
+        pkt_size = p.tab.ue_pkt_size[tu]; max_pkts = p.tab.ue_max_pkts[tu]; max_age = p.tab.ue_max_age[tu];
+        if (MODE != MODE_RESET) {
+            total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
+            front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
+        }
+        if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
+        if (hlen == D) { old_s = *rs; old_d = *rd; }
+        if (MODE != MODE_RESET)
+            traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
+    };
+    constexpr bool LATE_STATE = RANENV_LATE_STATE != 0 && STREAM == 0;
+    if (!LATE_STATE) load_state();
     // zero the (2) -> (3) rows
     for (int i = tid; i < GRP * 4 * GRP; i += (int)blockDim.x) (&rows[0][0][0])[i] = 0.0;
     for (int i = tid; i < GRP * GRP; i += (int)blockDim.x) (&sh.cnt[0][0])[i] = 0;
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
+    RANENV_STAMP(1);
     double my_full = 0.0, my_part = 0.0;
     if (QUADS) {
         double sfull[4], spart[4];
@@ -927,18 +1012,30 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     } else {
         if (MODE == MODE_STEP) {
             const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
-            row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part);
+#if RANENV_DIAG == 1
+            my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
+#elif RANENV_DIAG == 2
+            row_sums(se1, R, [=](int r) { return false; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part); my_part = (double)(us1 + uc1);
+#else
+            row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part);
+#endif
         } else if (MODE == MODE_DENSE) {
             const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-            row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part);
+            row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part);
         } else {
-            row_sums(se1, R, [](int) { return false; }, my_full, my_part);
+            row_sums(se1, R, [](int) { return false; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part);
         }
         __syncthreads();        // the (2) -> (3) rows were zeroed above by all threads
     }
 
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
+    RANENV_STAMP(2);
+    const double occ_prev = (double)total / (double)max_pkts;
+#if RANENV_DIAG == 3 || RANENV_DIAG == 5
+    if (act && my_full < -1.0) {
+#else
     if (act) {
+#endif
         if (MODE == MODE_DENSE) {
             const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
             bool seen = false;
@@ -1072,7 +1169,12 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
     }
     if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
+    RANENV_STAMP(3);
     __syncthreads();
+    RANENV_STAMP(4);
+#if RANENV_DIAG == 4 || RANENV_DIAG == 5
+    if (my_full >= -1.0) return;
+#endif
     if (tid >= GRP) return;                  // (3) is done by threads 0..15 (one wave)
 
     // ---- thread t < 16: slice at sorted position t (ib_sched.py:91) --------------------------------
@@ -1185,6 +1287,9 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
         if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
     }
+#if RANENV_DIAG == 9
+    if (tid == 0 && S > 9) p.st.policy_scores[(size_t)e * S + 9] = (double)__builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1215,6 +1320,7 @@ struct ranenv {
     Cached cache[6];
     int cache_next = 0;
     bool use_graph = true;
+    bool fuse = true;                   // allocation fused into the step kernel (RANENV_FUSE=0: two kernels)
     bool quads = false;                 // core variant: float4 quads (RANENV_QUADS=1)
     bool lds_dma = false;               // core variant: LDS-DMA staged SE stream (RANENV_LDS_DMA=1 enables)
     bool prof_on = false;               // ranenv_step_profiled: events around each kernel
@@ -1265,17 +1371,27 @@ void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
     const dim3 sblock((unsigned)(((kp.S * GRP) + WAVE - 1) / WAVE * WAVE));   // one thread per slot
     const dim3 cblock((unsigned)h->nt);
     hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;       // diagnostic per-kernel timing
-    if (ev) (void)hipEventRecord(ev[0], stream);
-    if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[1], stream);
     // LDS-DMA needs 16-byte aligned tiles: pool base, tile stride and (for explicit tiles) U*R*4
     const float *tiles = kp.se_tiles ? kp.se_tiles : kp.se_pool;
     const long long tstride = kp.se_tiles ? (long long)kp.U * kp.R : kp.se_stride;
     const bool aligned = (((size_t)tiles) & 15) == 0 && (tstride & 3) == 0;
-    if (h->quads) {
+    const bool use_lds = h->lds_dma && aligned;
+    // One kernel per TTI: the allocation is the first phase of the step kernel (>= 128 threads, so that
+    // the S*16 slots take at most two passes)
+    const bool fuse = MODE == MODE_STEP && h->fuse && !h->quads && !use_lds;
+    if (ev) (void)hipEventRecord(ev[0], stream);
+    if (MODE == MODE_STEP && !fuse) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    if (fuse) {
+        if constexpr (MODE == MODE_STEP) {
+            const dim3 fblock((unsigned)(h->nt < 2 * WAVE ? 2 * WAVE : h->nt));
+            if (kp.S * GRP > (int)fblock.x) hipLaunchKernelGGL((ranenv_core_kernel<MODE_STEP, false, 0, 2>), dim3(n_env), fblock, 0, stream, kp);
+            else hipLaunchKernelGGL((ranenv_core_kernel<MODE_STEP, false, 0, 1>), dim3(n_env), fblock, 0, stream, kp);
+        }
+    } else if (h->quads) {
         if (kp.R <= 256) hipLaunchKernelGGL((ranenv_core_kernel<MODE, true, 1>), dim3(n_env), cblock, 0, stream, kp);
         else hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 1>), dim3(n_env), cblock, 0, stream, kp);
-    } else if (h->lds_dma && aligned) {
+    } else if (use_lds) {
         const size_t ring = (size_t)LDS_NB * 32 * kp.U + 16;
         hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 2>), dim3(n_env), cblock, ring, stream, kp);
     } else {
@@ -1438,6 +1554,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         const char *env_q = getenv("RANENV_QUADS");
         h->quads = env_q && atoi(env_q) != 0;
         const char *env_l = getenv("RANENV_LDS_DMA");
+        const char *env_f = getenv("RANENV_FUSE");
+        h->fuse = env_f ? atoi(env_f) != 0 : true;
         h->lds_dma = env_l && atoi(env_l) != 0;   // opt-in: measured slower when fused (its in-flight data competes for LDS)
         const int need = h->quads ? (((U + 3) / 4) * 8 > U ? ((U + 3) / 4) * 8 : U) : U;
         h->nt = (need + WAVE - 1) / WAVE * WAVE;

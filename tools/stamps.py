@@ -1,4 +1,6 @@
-"""Diagnostic: per-phase s_memtime shares of wave 0 (needs RANENV_LIB=tools/diag9.so)."""
+"""Diagnostic: s_memtime phase stamps of the step kernel (build with -DRANENV_DIAG=9, run with
+RANENV_LIB=tools/diag9.so RANENV_FUSE=0).  Slots 0-4: wave 0 at entry / stream start / stream end /
+UE step end / after the barrier; slots 5-8: the same for wave 1; slot 9: end of the obs tail."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,9 +13,18 @@ env.reset()
 for _ in range(30):
     env.step()
 torch.cuda.synchronize()
-st = env.views()["policy_scores"].cpu().numpy()[:, :9]
-names = ["P0 load+barrier", "P1 policy", "P2 inter", "P3 intra", "P4 row loop", "P5 ue step", "P6 obs", "P7 reward"]
-d = np.diff(st, axis=1)
-print("median total cycles (s_memtime ticks @100MHz?)", np.median(st[:, 8]))
-for n, col in zip(names, d.T):
-    print(f"{n:18s} median {np.median(col):9.0f}  p90 {np.percentile(col, 90):9.0f}  share {np.median(col)/np.median(st[:,8])*100:5.1f}%")
+st = env.views()["policy_scores"].cpu().numpy()[:, :10] * 0.01      # us (100 MHz counter)
+t0 = st[:, 0].min()
+print("kernel span (first entry -> last end) %.1f us" % (st[:, 9].max() - t0))
+print("block entry times: p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(st[:, 0] - t0, [10, 50, 90, 100])))
+names = ["w0 prologue", "w0 stream", "w0 ue step", "w0 barrier wait"]
+for k, n in enumerate(names):
+    d = st[:, k + 1] - st[:, k]
+    print(f"{n:18s} median {np.median(d):7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f}")
+d = st[:, 9] - st[:, 4]
+print(f"{'w0 obs tail':18s} median {np.median(d):7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f}")
+for k, n in enumerate(["w1 prologue", "w1 stream", "w1 ue step"]):
+    d = st[:, k + 6] - st[:, k + 5]
+    print(f"{n:18s} median {np.median(d):7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f}")
+d = st[:, 9] - st[:, 0]
+print(f"{'block lifetime':18s} median {np.median(d):7.2f}  p10 {np.percentile(d, 10):7.2f}  p90 {np.percentile(d, 90):7.2f}")
