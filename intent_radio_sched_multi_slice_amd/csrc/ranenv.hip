@@ -1320,7 +1320,7 @@ struct ranenv {
     Cached cache[6];
     int cache_next = 0;
     bool use_graph = true;
-    bool fuse = true;                   // allocation fused into the step kernel (RANENV_FUSE=0: two kernels)
+    bool fuse = false;                  // allocation fused into the step kernel (RANENV_FUSE=1; default: two kernels)
     bool quads = false;                 // core variant: float4 quads (RANENV_QUADS=1)
     bool lds_dma = false;               // core variant: LDS-DMA staged SE stream (RANENV_LDS_DMA=1 enables)
     bool prof_on = false;               // ranenv_step_profiled: events around each kernel
@@ -1555,7 +1555,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         h->quads = env_q && atoi(env_q) != 0;
         const char *env_l = getenv("RANENV_LDS_DMA");
         const char *env_f = getenv("RANENV_FUSE");
-        h->fuse = env_f ? atoi(env_f) != 0 : true;
+        h->fuse = env_f ? atoi(env_f) != 0 : false;   // measured: 102 us fused vs 99 us as two kernels
         h->lds_dma = env_l && atoi(env_l) != 0;   // opt-in: measured slower when fused (its in-flight data competes for LDS)
         const int need = h->quads ? (((U + 3) / 4) * 8 > U ? ((U + 3) / 4) * 8 : U) : U;
         h->nt = (need + WAVE - 1) / WAVE * WAVE;

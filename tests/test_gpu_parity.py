@@ -198,15 +198,14 @@ def test_batch_vs_oracle(policy, intra, size):
     dict(S=16, U=128, R=300, G=3, Us=16),  # three leaves (150 -> 72+78 | 150), full slot grid
     dict(S=6, U=64, R=408, G=8, Us=11),    # four leaves, G does not divide R
 ])
-@pytest.mark.parametrize("variant", ["default", "quads", "lds"])
-def test_shapes_vs_oracle(shape, variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["external", "device"])
+def test_shapes_vs_oracle(shape, variant):
     """Other sizes than the BASELINE ones: every numpy pairwise-sum shape of the SE row reduction,
-    partial quads, a full 16 x 16 slot grid; for each of the three SE-stream variants."""
+    a partial last wave of UEs, a full 16 x 16 slot grid; with the caller's scores / schedulers
+    (alloc kernel every TTI) and with MAPF + PF on the device (allocation made by the post kernel)."""
     _need_gpu()
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     from oracle import pyoracle
-    monkeypatch.setenv("RANENV_QUADS", "1" if variant == "quads" else "0")
-    monkeypatch.setenv("RANENV_LDS_DMA", "1" if variant == "lds" else "0")
     S, U, R, G, Us = (shape[k] for k in ("S", "U", "R", "G", "Us"))
     tabs = generate_scaled_scenarios(3, seed=5, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=max(1, S // 2),
                                      min_ues=max(1, Us // 3))
@@ -221,17 +220,23 @@ def test_shapes_vs_oracle(shape, variant, monkeypatch):
     trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
     env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
     env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
-    env.set_policy(0, 255)
+    env.set_policy(0, 255) if variant == "external" else env.set_policy(2, 1)
     ocfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
     oenvs = []
     for b in range(B):
         o = pyoracle.OracleEnv(ocfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
     env.reset()
     for t in range(steps):
-        sc = rng.uniform(-1, 1, (B, S)); ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
-        obs, rew, done = env.step(sc, ic)
+        if variant == "external":
+            sc = rng.uniform(-1, 1, (B, S)); ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+            obs, rew, done = env.step(sc, ic)
+        else:
+            sc = np.stack([o.policy_mapf() for o in oenvs]); ic = np.ones((B, S), dtype=np.uint8)
+            obs, rew, done = env.step()
         g = {k: x.cpu().numpy() for k, x in env.views().items()}
         for b, o in enumerate(oenvs):
+            _, count, _ = o.action_format(sc[b], ic[b], want_dense=False)
+            assert np.array_equal(g["rb_count"][b], count), (shape, variant, t, b)
             o.step(sc[b], ic[b], se_pool[b * steps + t], trf[b * steps + t])
             raw = o.raw()
             for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
@@ -240,4 +245,77 @@ def test_shapes_vs_oracle(shape, variant, monkeypatch):
             np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=OBS_TOL)
             np.testing.assert_allclose(obs["obs_intra"][b].cpu().numpy(), oo["obs_intra"], rtol=0, atol=OBS_TOL)
             np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=REW_TOL)
+    env.close()
+
+
+def test_policy_switching_vs_oracle():
+    """The allocation of a TTI is made either by the alloc kernel (caller's scores, or no stored
+    allocation) or by the post kernel of the TTI before (device policy).  Walk through every
+    hand-over: external -> MARR+RR -> MAPF+PF (set_policy in between) -> external -> dense -> MAPF+PF
+    -> masked reset -> MT."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    S, U, R, G, Us, B = 5, 25, 135, 1, 5, 8
+    tabs = generate_scaled_scenarios(4, seed=11, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=3, min_ues=2)
+    plan = (["ext"] * 3 + ["marr_rr"] * 3 + ["mapf_pf"] * 3 + ["ext"] * 2 + ["dense"] * 2 + ["mapf_pf"] * 2 +
+            ["reset"] + ["mapf_mt"] * 3 + ["ext"] + ["marr_rr"] * 2)
+    steps = len(plan)
+    rng = np.random.default_rng(21)
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    se_pool = np.stack([se_tile(70, t, U, R) for t in range(B * steps)])
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
+    env = _env(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+               n_scenarios=tabs.n_scenarios, max_steps=steps)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(_rb_major(se_pool), device=env.device))
+    env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
+    oenvs = _oracle_batch(tabs, scen, S, U, R, G, Us, steps)
+    env.reset()
+    for b in range(B):
+        oenvs[b].reset(se_pool[b * steps])
+    dev = {"marr_rr": (1, 0), "mapf_pf": (2, 1), "mapf_mt": (2, 2)}
+    t = 0                                    # TTIs since the trace started (a reset does not advance it)
+    t0 = np.zeros(B, dtype=np.int64)
+    for what in plan:
+        if what == "reset":
+            mask = (np.arange(B) % 2 == 0).astype(np.uint8)
+            env.reset(env_mask=mask)
+            for b in np.nonzero(mask)[0]:
+                t0[b] = t
+                oenvs[b].reset(se_pool[b * steps + 0])   # a reset env replays its trace from the offset
+            continue
+        idx = [b * steps + int(t - t0[b]) for b in range(B)]
+        if what == "ext":
+            env.set_policy(0, 255)
+            sc = rng.uniform(-1, 1, (B, S)); ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+            obs, rew, done = env.step(sc, ic)
+        elif what == "dense":
+            sc = rng.uniform(-1, 1, (B, S)); ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+            dense = np.zeros((B, U, R), dtype=np.uint8)
+            for b in range(B):
+                start, count, _ = oenvs[b].action_format(sc[b], ic[b], want_dense=False)
+                for u in range(U):
+                    dense[b, u, start[u]:start[u] + count[u]] = 1
+            tiles = np.stack([_rb_major(se_pool[i][None])[0] for i in idx])
+            obs, rew, done = env.step_dense(dense, trf[idx].astype(np.float64), tiles)
+        else:
+            pol, intra = dev[what]
+            env.set_policy(pol, intra)
+            sc = np.stack([o.policy_marr() if pol == 1 else o.policy_mapf() for o in oenvs])
+            ic = np.full((B, S), intra, dtype=np.uint8)
+            obs, rew, done = env.step()
+        g = {k: x.cpu().numpy() for k, x in env.views().items()}
+        for b, o in enumerate(oenvs):
+            _, count, _ = o.action_format(sc[b], ic[b], want_dense=False)
+            assert np.array_equal(g["rb_count"][b], count), (what, t, b)
+            o.step(sc[b], ic[b], se_pool[idx[b]], trf[idx[b]])
+            raw = o.raw()
+            for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (what, t, b, name)
+            oo = o.obs()
+            np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(obs["obs_intra"][b].cpu().numpy(), oo["obs_intra"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=REW_TOL)
+        t += 1
     env.close()

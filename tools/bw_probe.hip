@@ -106,6 +106,101 @@ __global__ void __launch_bounds__(128) kD(const float *pool, const int *tile_of,
     if (tid < U) out[(size_t)blockIdx.x * U + u] = acc;
 }
 
+
+// E: the env-step form: buffer loads, scalar row offset, lane = UE, DEPTH rows in flight, f64 accumulate
+template <int DEPTH>
+__global__ void __launch_bounds__(256) kE(const float *pool, const int *tile_of, float *out, int U, int R, int pitch)
+{
+    const float *tile = pool + (size_t)tile_of[blockIdx.x] * pitch * R;
+    const int u = threadIdx.x < U ? threadIdx.x : U - 1;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, pitch * R * 4, 0x00020000);
+    const int voff = u * 4, rb = pitch * 4;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float q[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) q[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, d * rb, 0));
+#pragma unroll 1
+    for (int r = 0; r < R; r += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (r + d < R) {
+                acc[d & 7] += (double)q[d];
+                const int rn = r + d + DEPTH;
+                if (rn < R) q[d] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rn * rb, 0));
+            }
+        }
+    }
+    double t = 0; for (int j = 0; j < 8; j++) t += acc[j];
+    if (threadIdx.x < U) out[(size_t)blockIdx.x * U + u] = (float)t;
+}
+
+// F: one wave covers whole rows with 8-byte loads (lane i = UEs 2i, 2i+1); the NW waves of the workgroup
+// take the rows r = w (mod NW)
+template <int DEPTH, int NW>
+__global__ void __launch_bounds__(256) kF(const float *pool, const int *tile_of, float *out, int U, int R)
+{
+    const float *tile = pool + (size_t)tile_of[blockIdx.x] * U * R;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane * 2 < U ? lane : 0;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
+    const int voff = c * 8, rb = U * 4;
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    float2 q[DEPTH];
+    auto ld = [&](int k) { return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (k * NW + w) * rb, 0)); };
+    const int n = (R - w + NW - 1) / NW;      // rows of this wave
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) if (d < n) q[d] = ld(d);
+#pragma unroll 1
+    for (int k = 0; k < n; k += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (k + d < n) {
+                a0[d & 3] += (double)q[d].x; a1[d & 3] += (double)q[d].y;
+                if (k + d + DEPTH < n) q[d] = ld(k + d + DEPTH);
+            }
+        }
+    }
+    const double t0 = (a0[0] + a0[1]) + (a0[2] + a0[3]), t1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    if (lane * 2 < U) { out[(size_t)blockIdx.x * U + lane * 2] = (float)(t0 + w); out[(size_t)blockIdx.x * U + lane * 2 + 1] = (float)t1; }
+}
+
+// G: 16 bytes per lane along U (lane i = UEs 4i..4i+3), a wave-load covers 2.5 rows of 400 B: lanes 0..24 row k,
+// 25..49 row k+1 (NW waves take alternating row pairs)
+template <int DEPTH, int NW>
+__global__ void __launch_bounds__(256) kG(const float *pool, const int *tile_of, float *out, int U, int R)
+{
+    const float *tile = pool + (size_t)tile_of[blockIdx.x] * U * R;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int C = U / 4;                       // float4 per row
+    const int RPW = 64 / C;                    // rows per wave-load (2 for U = 100)
+    const int sub = lane / C < RPW ? lane / C : RPW - 1, c = lane % C;
+    const bool act = lane < RPW * C;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
+    const int rb = U * 4;
+    const int voff = sub * rb + c * 16;
+    double a[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) a[i][j] = 0;
+    float4 q[DEPTH];
+    const int n = (R / RPW - w + NW - 1) / NW;   // row groups of this wave
+    auto ld = [&](int k) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (k * NW + w) * RPW * rb, 0)); };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) if (d < n) q[d] = ld(d);
+#pragma unroll 1
+    for (int k = 0; k < n; k += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (k + d < n) {
+                a[d & 3][0] += (double)q[d].x; a[d & 3][1] += (double)q[d].y; a[d & 3][2] += (double)q[d].z; a[d & 3][3] += (double)q[d].w;
+                if (k + d + DEPTH < n) q[d] = ld(k + d + DEPTH);
+            }
+        }
+    }
+    double t = 0;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) t += a[i][j];
+    if (act) out[(size_t)blockIdx.x * U + (lane % U)] = (float)t;
+}
+
 int main()
 {
     const int U = 100, R = 135, B = 4096, T = 40000;
@@ -138,6 +233,18 @@ int main()
     run("D lds-dma ring 3", [&] { hipLaunchKernelGGL((kD<3, 2>), dim3(B), dim3(128), 3 * 32 * U, 0, pool, tile_of, out, U, R); });
     run("D lds-dma ring 4", [&] { hipLaunchKernelGGL((kD<4, 2>), dim3(B), dim3(128), 4 * 32 * U, 0, pool, tile_of, out, U, R); });
     run("D lds-dma ring 6", [&] { hipLaunchKernelGGL((kD<6, 2>), dim3(B), dim3(128), 6 * 32 * U, 0, pool, tile_of, out, U, R); });
+
+    run("E buffer dword d16 (128 thr)", [&] { hipLaunchKernelGGL(kE<16>, dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R, U); });
+    run("E buffer dword d24 (128 thr)", [&] { hipLaunchKernelGGL(kE<24>, dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R, U); });
+    run("E buffer dword d48 (128 thr)", [&] { hipLaunchKernelGGL(kE<48>, dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R, U); });
+    run("F b64 full rows 2 waves d12", [&] { hipLaunchKernelGGL((kF<12, 2>), dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("F b64 full rows 2 waves d24", [&] { hipLaunchKernelGGL((kF<24, 2>), dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("F b64 full rows 1 wave  d24", [&] { hipLaunchKernelGGL((kF<24, 1>), dim3(B), dim3(64), 0, 0, pool, tile_of, out, U, R); });
+    run("F b64 full rows 4 waves d12", [&] { hipLaunchKernelGGL((kF<12, 4>), dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
+    run("G b128 2 rows/load 2 waves d8", [&] { hipLaunchKernelGGL((kG<8, 2>), dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("G b128 2 rows/load 2 waves d16", [&] { hipLaunchKernelGGL((kG<16, 2>), dim3(B), dim3(128), 0, 0, pool, tile_of, out, U, R); });
+    run("G b128 2 rows/load 1 wave d16", [&] { hipLaunchKernelGGL((kG<16, 1>), dim3(B), dim3(64), 0, 0, pool, tile_of, out, U, R); });
+    run("G b128 2 rows/load 4 waves d8", [&] { hipLaunchKernelGGL((kG<8, 4>), dim3(B), dim3(256), 0, 0, pool, tile_of, out, U, R); });
     run("C flat float4", [&] { hipLaunchKernelGGL(kC, dim3(B), dim3(256), 0, 0, (const float4 *)pool, tile_of, out, U * R / 4); });
     return 0;
 }

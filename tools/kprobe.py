@@ -1,4 +1,4 @@
-"""Per-kernel time of the two-kernel step (RANENV_FUSE=0) from hipEvents: python tools/kprobe.py [batch]"""
+"""Per-kernel time of one TTI from hipEvents: python tools/kprobe.py [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

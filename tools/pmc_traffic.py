@@ -2,7 +2,7 @@
 
     python tools/pmc_traffic.py <fetch_dir> <write_dir> <batch> <config> <out.json>
 
-HBM bytes per TTI = sum over the three step kernels of (2 * FETCH_SIZE + WRITE_SIZE) KiB.
+HBM bytes per TTI = sum over the step's kernels of (2 * FETCH_SIZE + WRITE_SIZE) KiB.
 The factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section:
 TCC_EA0_RDREQ counts 128-B requests at 64 B); it is calibrated here on this kernel's own
 known byte count: the SE stream alone is 4*U*R bytes per env and dominates the reads.
@@ -12,7 +12,7 @@ import collections, csv, glob, json, sys
 
 def per_kernel(d, counter):
     agg = collections.defaultdict(list)
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
             if "ranenv_" in kn and r["Counter_Name"] == counter and "<2," not in kn:
@@ -26,6 +26,6 @@ kib = 1024.0
 total = sum(2.0 * v * kib for v in fetch.values()) + sum(v * kib for v in write.values())
 json.dump({"batch": int(batch), "config": int(config), "hbm_bytes_per_launch": total,
            "fetch_size_kib_raw": fetch, "write_size_kib": write,
-           "note": "per TTI (alloc+core+obs); FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction"},
+           "note": "per TTI (all kernels of one step); FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction"},
           open(out, "w"), indent=1)
 print(json.dumps({"hbm_bytes_per_launch": total, "fetch": fetch, "write": write}))
