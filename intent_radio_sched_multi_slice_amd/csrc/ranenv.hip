@@ -43,7 +43,8 @@
 #define DEVFN __device__ __forceinline__
 
 #ifndef RANENV_DIAG
-#define RANENV_DIAG 0   /* diagnostic builds only: 1-4 skip a phase, 9 stamps s_memtime per phase */
+#define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the core kernel, 6-7 of the alloc kernel,
+                           9 stamps s_memtime per phase (tools/stamps.py, tools/kprobe.py) */
 #endif
 
 namespace {
@@ -117,19 +118,31 @@ DEVFN double np_sum16(const double (&xin)[16], int n)
 }
 
 // the same over a row of 16 doubles in LDS whose entries at positions >= n are +0.0 (every writer
-// in this file zero-pads its rows), so no per-element select is needed; all 16 reads issue back to back
+// in this file zero-pads its rows), so no per-element select is needed; all 16 reads issue back to back.
+// Of numpy's three shapes only those some lane of the wave needs are evaluated (wave-uniform tests):
+// an instruction costs the same with one active lane as with 64.
 DEVFN double np_sum16_lds(const double *row, int n)
 {
     double x[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = row[j];
-    const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
-    double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    double res = 0.0;
+    if (__builtin_amdgcn_ballot_w64(n < 8) != 0) {
+        const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
+        res = n < 8 ? seq : res;
+    }
+    if (__builtin_amdgcn_ballot_w64(n >= 8 && n < 16) != 0) {
+        double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
 #pragma unroll
-    for (int j = 8; j < 15; j++) t8 += x[j];
-    const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
-                       (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
-    return n < 8 ? seq : (n < 16 ? t8 : t16);
+        for (int j = 8; j < 15; j++) t8 += x[j];
+        res = (n >= 8 && n < 16) ? t8 : res;
+    }
+    if (__builtin_amdgcn_ballot_w64(n >= 16) != 0) {
+        const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
+                           (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
+        res = n >= 16 ? t16 : res;
+    }
+    return res;
 }
 
 DEVFN bool d_apply_op(int op, double a, double b)
@@ -459,6 +472,9 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen, in
         active = si[0]; nues1 = si[2]; bsize = si[3]; msg = si[5]; sorted = si[7];
     }
     __syncthreads();
+#if RANENV_DIAG == 7
+    if (p.B > 0) { if (ok1) p.st.policy_scores[(size_t)e * S + s1] = rows[s1][0][0] + rows[s1][1][1]; return; }
+#endif
     if (tid < WAVE) {            // wave 0; the other waves go straight to the barrier below
         double score = -1.0;
         if (mapf) {
@@ -626,9 +642,24 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 {
     __shared__ SharedAlloc sa;
     const int e = p.e0 + blockIdx.x;
+#if RANENV_DIAG == 6
+    if (p.B > 0) return;       // launch cost only
+#endif
     const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
     const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
     alloc_phase<1>(p, sa, e, sc, hlen, nullptr, nullptr);
+}
+
+// The same with 128 threads and two passes over the slots: two waves per workgroup instead of three
+// or four, so that all 16 workgroups a CU gets at the headline batch are resident at once (the kernel
+// is a chain of dependent steps; what it needs is more envs in flight, not more lanes per env).
+__global__ void __launch_bounds__(2 * WAVE) ranenv_alloc2_kernel(const KP p)
+{
+    __shared__ SharedAlloc sa;
+    const int e = p.e0 + blockIdx.x;
+    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
+    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
+    alloc_phase<2>(p, sa, e, sc, hlen, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1036,6 +1067,20 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 #else
     if (act) {
 #endif
+        // slice row for the drift (L2-resident tables): requested first, it lands while the buffer is stepped
+        int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
+        int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
+        double pv[3] = {0.0, 0.0, 0.0};
+        if (slc >= 0) {
+            const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
+            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
+                po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
+                pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
+            }
+        }
         if (MODE == MODE_DENSE) {
             const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
             bool seen = false;
@@ -1106,20 +1151,6 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         if (MODE != MODE_STEP) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
-        // slice row for the drift: L2-resident table reads
-        int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
-        int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
-        double pv[3] = {0.0, 0.0, 0.0};
-        if (slc >= 0) {
-            const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
-            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
-                po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
-                pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
-            }
-        }
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
         double dres[3] = {0.0, 0.0, 0.0};
         if (slc >= 0 && has_req) {
@@ -1272,18 +1303,15 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         double rew = np_sum16_lds(xr[2], m_sel) / (double)m_sel;
         if (mode_sel == 1) rew -= 1.0;
         if (p.reward) p.reward[(size_t)e * (S + 1)] = rew;
-        const ranenv_episode ep = p.episodes[e];
-        const int hlen0 = (MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET)) ? 0 : p.st.hist_len[e];
-        const int npush = p.st.n_push[e];
-        const int step_new = (MODE == MODE_RESET) ? 0 : p.st.step_no[e] + 1;
+        // per-env counters: everything was read as a scalar at kernel entry (hlen already reflects a cleared window)
+        const int step_new = (MODE == MODE_RESET) ? 0 : t + 1;
         p.st.step_no[e] = step_new;
-        p.st.hist_len[e] = hlen0 < D ? hlen0 + 1 : D;
+        p.st.hist_len[e] = hlen_new;
         p.st.n_push[e] = npush + 1 == D ? 0 : npush + 1;
         if (MODE == MODE_RESET) { p.st.se_pos[e] = ep.se_offset; p.st.trf_pos[e] = ep.trf_offset; }
         else {
-            const int sp = p.st.se_pos[e], tp = p.st.trf_pos[e];
-            p.st.se_pos[e] = sp + 1 >= ep.se_len ? 0 : sp + 1;
-            p.st.trf_pos[e] = tp + 1 >= ep.trf_len ? 0 : tp + 1;
+            p.st.se_pos[e] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
+            p.st.trf_pos[e] = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
         }
         if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
     }
@@ -1320,6 +1348,7 @@ struct ranenv {
     Cached cache[6];
     int cache_next = 0;
     bool use_graph = true;
+    bool alloc2 = false;                // alloc kernel with 128 threads and two slot passes (RANENV_ALLOC2=1)
     bool fuse = false;                  // allocation fused into the step kernel (RANENV_FUSE=1; default: two kernels)
     bool quads = false;                 // core variant: float4 quads (RANENV_QUADS=1)
     bool lds_dma = false;               // core variant: LDS-DMA staged SE stream (RANENV_LDS_DMA=1 enables)
@@ -1380,7 +1409,10 @@ void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
     // the S*16 slots take at most two passes)
     const bool fuse = MODE == MODE_STEP && h->fuse && !h->quads && !use_lds;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    if (MODE == MODE_STEP && !fuse) hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
+    if (MODE == MODE_STEP && !fuse) {
+        if (h->alloc2 && kp.S * GRP > 2 * WAVE) hipLaunchKernelGGL(ranenv_alloc2_kernel, dim3(n_env), dim3(2 * WAVE), 0, stream, kp);
+        else hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
+    }
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (fuse) {
         if constexpr (MODE == MODE_STEP) {
@@ -1554,6 +1586,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         const char *env_q = getenv("RANENV_QUADS");
         h->quads = env_q && atoi(env_q) != 0;
         const char *env_l = getenv("RANENV_LDS_DMA");
+        const char *env_a = getenv("RANENV_ALLOC2");
+        h->alloc2 = env_a ? atoi(env_a) != 0 : false;   // measured: 28 us against 26 us for one pass with 3 waves
         const char *env_f = getenv("RANENV_FUSE");
         h->fuse = env_f ? atoi(env_f) != 0 : false;   // measured: 102 us fused vs 99 us as two kernels
         h->lds_dma = env_l && atoi(env_l) != 0;   // opt-in: measured slower when fused (its in-flight data competes for LDS)
