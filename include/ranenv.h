@@ -32,7 +32,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls on one
  *     handle must be serialised by the caller; work is enqueued, not synchronised.
  *   - there is no CPU fallback: if no gfx950 device/kernel image is usable the calls fail.
- *   - sizes supported by this build: S <= 16, max_ues_slice <= 16, U <= 1024, R <= 512,
+ *   - sizes supported by this build: S <= 16, max_ues_slice <= 16, U <= 256, R <= 512,
  *     hist_depth <= 64; packet counts must stay below 2^31 (checked when scenarios are loaded).
  *   - SE tiles are RB-major: element (rb r, ue u) of a tile at offset r*U + u.
  */

@@ -1532,11 +1532,11 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     *out = nullptr;
     if (cfg->abi_version != RANENV_ABI_VERSION) return fail(nullptr, RANENV_E_INVALID, "abi_version %d != %d", cfg->abi_version, RANENV_ABI_VERSION);
     const int S = cfg->n_slices, U = cfg->n_ues, R = cfg->n_rbs, Us = cfg->max_ues_slice;
-    if (cfg->batch < 1 || S < 1 || S > GRP || U < 1 || U > 1024 || R < 1 || R > 512 || Us < 1 || Us > GRP ||
+    if (cfg->batch < 1 || S < 1 || S > GRP || U < 1 || U > ALLOC_NT || R < 1 || R > 512 || Us < 1 || Us > GRP ||
         cfg->rbs_per_rbg < 1 || cfg->rbs_per_rbg > R || cfg->hist_depth < 1 || cfg->hist_depth > 64 ||
         cfg->max_age_cap < 1 || cfg->max_age_cap > 65000 || cfg->max_steps < 1 || cfg->n_scenarios < 1)
         return fail(nullptr, RANENV_E_INVALID,
-                    "unsupported sizes: need 1<=S<=16, 1<=U<=1024, 1<=R<=512, 1<=Us<=16, 1<=G<=R, 1<=hist_depth<=64");
+                    "unsupported sizes: need 1<=S<=16, 1<=U<=256, 1<=R<=512, 1<=Us<=16, 1<=G<=R, 1<=hist_depth<=64");
     if (!(cfg->bandwidth_hz > 0.0)) return fail(nullptr, RANENV_E_INVALID, "bandwidth_hz must be positive");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1593,7 +1593,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         h->lds_dma = env_l && atoi(env_l) != 0;   // opt-in: measured slower when fused (its in-flight data competes for LDS)
         const int need = h->quads ? (((U + 3) / 4) * 8 > U ? ((U + 3) / 4) * 8 : U) : U;
         h->nt = (need + WAVE - 1) / WAVE * WAVE;
-        if (h->nt > ALLOC_NT) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build steps at most 128 UEs per env"); }
+        if (h->nt > ALLOC_NT) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build steps at most 256 UEs per env"); }
     }
     h->lds_bytes = GRP * 4 * GRP * 8 + 3 * GRP * 8;   // static LDS of the widest kernel (obs)
     {   // fail at create, not at the first step, when the code object has no gfx950 image

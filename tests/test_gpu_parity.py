@@ -197,6 +197,7 @@ def test_batch_vs_oracle(policy, intra, size):
     dict(S=4, U=37, R=100, G=5, Us=12),    # one leaf with a tail, U not a multiple of 4
     dict(S=16, U=128, R=300, G=3, Us=16),  # three leaves (150 -> 72+78 | 150), full slot grid
     dict(S=6, U=64, R=408, G=8, Us=11),    # four leaves, G does not divide R
+    dict(S=16, U=256, R=64, G=1, Us=16),   # the largest UE count of this build: four waves per env
 ])
 @pytest.mark.parametrize("variant", ["external", "device"])
 def test_shapes_vs_oracle(shape, variant):
