@@ -1,9 +1,9 @@
 // ranenv.hip -- MI355X (gfx950) implementation of the C ABI in include/ranenv.h.
 //
-// One workgroup steps one environment for one TTI.  Thread u of the workgroup owns UE u for
-// the whole step: it streams UE u's spectral-efficiency row, updates UE u's packet queue and
-// computes UE u's intent drift, all in registers.  Only slice-level work (inter-slice RBG
-// split, intra-slice RR/PF/MT, per-slice means, reward) goes through LDS.
+// One TTI = two kernels, one workgroup per environment each.  alloc: thread = (slice, UE position)
+// slot, turns scores into RB ranges (inter-slice RBG split, intra-slice RR/PF/MT).  core: thread u owns
+// UE u -- it streams UE u's spectral-efficiency row, updates UE u's packet queue and computes UE u's
+// intent drift, all in registers; per-slice means, observation rows and rewards then go through LDS.
 //
 // HBM layout (B envs, S slices, U UEs, R RBs, L = max_age_cap+1, D = hist_depth):
 //   SE pool        float32 [tile][R][U]   RB-major: at RB r the U lanes of a workgroup read U
@@ -19,6 +19,8 @@
 //                                          (oracle/ranenv_oracle.c) while a step touches only the
 //                                          inserted / expired / drained entries.
 //   10-TTI window  int32   [B][D][U] x2   pkt_effective_thr and dropped_pkts of the last D pushes
+//   slot records   [B][S*16]               queue length, window sum, mean SE in (slice, position) order:
+//                                          written by core, read coalesced by the next alloc
 //   scenario pool  small SoA tables, shared by all envs replaying a scenario (L2 resident)
 //
 // Reference behaviour restated here (file:line under lasseufpa/intent_radio_sched_multi_slice):
@@ -71,15 +73,14 @@ struct State {
     int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
     int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
-    double *se_part;            // [B][U] sum of SE over the UE's allocated RBs, stream -> ue
-    // slot-ordered records, slot = slice*16 + position: written by core (alloc for rbc), read
-    // coalesced by alloc and obs                                         [B][S*16]
-    int32_t *slot_q; int64_t *slot_ws; double *slot_sem; double *slot_d0, *slot_d1, *slot_d2; int32_t *slot_rbc;
+    // slot-ordered records, slot = slice*16 + position: written by the core kernel's UE lanes, read
+    // coalesced by the next TTI's alloc kernel                           [B][S*16]
+    int32_t *slot_q; int64_t *slot_ws; double *slot_sem;
 };
 
 struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
-    int e0;   // first env of this launch (the batch is stepped in chunks on parallel streams)
+    int e0;   // first env of this launch
     double bw_hz, bw_per_rb, over, norm_traffic, norm_ues, norm_se;
     Tables tab;
     State st;
@@ -99,25 +100,10 @@ struct KP {
 // ---------------------------------------------------------------------------------------------
 DEVFN bool d_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * fabs(b)); }
 
-// numpy pairwise_sum of n <= 16 doubles held in registers (x[j] for j >= n is ignored).
-// Missing elements count as +0.0, which turns numpy's three shapes for n <= 16 (n < 8 plain loop;
-// 8 <= n < 16 tree of the first 8 + sequential tail; n == 16 tree of 8 pair sums) into plain
-// expressions, since x + 0.0 == x exactly.
-DEVFN double np_sum16(const double (&xin)[16], int n)
-{
-    double x[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = j < n ? xin[j] : 0.0;
-    const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
-    double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-#pragma unroll
-    for (int j = 8; j < 15; j++) t8 += x[j];
-    const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
-                       (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
-    return n < 8 ? seq : (n < 16 ? t8 : t16);
-}
-
-// the same over a row of 16 doubles in LDS whose entries at positions >= n are +0.0 (every writer
+// numpy pairwise_sum of n <= 16 doubles: missing elements count as +0.0, which turns numpy's three
+// shapes for n <= 16 (n < 8 plain loop; 8 <= n < 16 tree of the first 8 + sequential tail; n == 16
+// tree of 8 pair sums) into plain expressions, since x + 0.0 == x exactly.
+// The row of 16 doubles sits in LDS and its entries at positions >= n are +0.0 (every writer
 // in this file zero-pads its rows), so no per-element select is needed; all 16 reads issue back to back.
 // Of numpy's three shapes only those some lane of the wave needs are evaluated (wave-uniform tests):
 // an instruction costs the same with one active lane as with 64.
@@ -165,8 +151,8 @@ constexpr int GRP = 16;   // lanes per (env) group in alloc1/obs and per (env, s
 // Lane u reduces row u of an RB-major tile (element r at byte offset r*U*4 + u*4).  Loads go through
 // a wave-uniform buffer descriptor: the row offset is a scalar, the lane offset one VGPR, so a load
 // costs no vector address arithmetic.  SE_NQ groups of 8 loads rotate through fixed registers (no
-// moves), i.e. up to 8*SE_NQ loads per lane are in flight: the per-workgroup time is a chain of memory
-// round trips (~1.8 us each under load), and the row costs ceil(R / (8*SE_NQ)) of them.
+// moves), i.e. up to 8*SE_NQ loads per lane are in flight while a group is being summed (measured:
+// 16, 24 and 48 give the same kernel time within 1 us).
 //
 // Summation order = numpy's pairwise_sum (see np_sum_lds): the row is cut into leaves of <= 128
 // RBs by halving at multiples of 8; inside a leaf, accumulator j takes the elements j mod 8, the
@@ -195,11 +181,11 @@ DEVFN RowPlan make_row_plan(int n)
     return pl;
 }
 
+#ifndef RANENV_SE_AUX
+#define RANENV_SE_AUX 0   /* cache policy bits of the SE loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1) */
+#endif
 #ifndef RANENV_SE_DEPTH
 #define RANENV_SE_DEPTH 3
-#endif
-#ifndef RANENV_LATE_STATE
-#define RANENV_LATE_STATE 0
 #endif
 constexpr int SE_NQ = RANENV_SE_DEPTH;   // 8-row groups in flight per lane
 
@@ -214,7 +200,7 @@ struct SeStream {
         for (int j = 0; j < 8; j++) {
             const int r = r0 + j;
             const int rr = r < r_last ? r : r_last;                       // scalar clamp: always in bounds
-            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rr * row_bytes, 0));
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rr * row_bytes, RANENV_SE_AUX));
         }
     }
     DEVFN void init(const float *tile, int U, int u, int R)
@@ -231,10 +217,8 @@ struct SeStream {
 // exactly, so the result is numpy's bit for bit while the loop body stays branch-free; the only
 // control flow per 8-group is one wave-uniform "leaf finished?" test.  Only the row's last leaf can
 // have a tail (R mod 8 elements); it is added sequentially after the loop, as numpy does.
-// late() is called once, before the last pass over the queue: what it loads lands under the last
-// round trip of the stream, in registers the drained part of the queue no longer needs.
-template <typename InFn, typename LateFn>
-DEVFN void row_sums(SeStream &st, int R, InFn in, LateFn late, double &full, double &part)
+template <typename InFn>
+DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
 {
     const RowPlan pl = make_row_plan(R);
     const int tail = R & 7, G = R >> 3;
@@ -289,108 +273,12 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, LateFn late, double &full, dou
             }
         }
     };
-    if (G == 0) late();
 #pragma unroll 1
-    for (int gi = 0; gi < G; gi += SE_NQ) {
-        if (gi + SE_NQ >= G) late();       // wave-uniform: the last turn of the queue
-        pass(gi);
-    }
+    for (int gi = 0; gi < G; gi += SE_NQ) pass(gi);
     if (tail > 0) {
         const int m = G % SE_NQ;
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) if (m == d) add_tail(st.q[d], G * 8);
-    }
-    if (pl.n_leaves == 1) { full = lf; part = lg; return; }
-    full = lf + rf; part = lg + rg;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Two lanes per SE row: lane h of a UE's pair owns numpy's accumulators 4h..4h+3, i.e. rows
-// 4h..4h+3 of every 8-row group.  The leaf result is ((r0+r1)+(r2+r3)) from lane 0 plus
-// ((r4+r5)+(r6+r7)) from lane 1 -- exactly numpy's combination tree, one cross-lane add -- so the sums
-// are bit-identical to the one-lane form while each lane's dependent chain, accumulator registers
-// and loads per group are halved; the freed registers hold a 6-group-deep load queue.
-// ---------------------------------------------------------------------------------------------
-struct SeStream2 {
-    float q[6][4];
-    float tl[7];                   // the row's tail (R mod 8 elements), same for both lanes
-    __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
-    int voff, voff_u, row_bytes;
-
-    DEVFN void load(float (&dst)[4], int r0)
-    {
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-            dst[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (r0 + a) * row_bytes, 0));
-    }
-    DEVFN void init(const float *tile, int U, int u, int h, int R)
-    {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
-        voff_u = u * 4; voff = (4 * h * U + u) * 4; row_bytes = U * 4;
-        const int G = R >> 3, tail = R & 7;
-#pragma unroll
-        for (int d = 0; d < 6; d++) if (d < G) load(q[d], d * 8);
-#pragma unroll
-        for (int j = 0; j < 7; j++)
-            tl[j] = j < tail ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_u, (G * 8 + j) * row_bytes, 0)) : 0.0f;
-    }
-};
-
-// in(r) is evaluated for the lane's own rows; both lanes of a pair return the same sums.
-template <typename InFn>
-DEVFN void row_sums2(SeStream2 &st, int R, int h, InFn in, double &full, double &part)
-{
-    const RowPlan pl = make_row_plan(R);
-    const int tail = R & 7, G = R >> 3;
-    double f[4] = {0.0, 0.0, 0.0, 0.0}, g[4] = {0.0, 0.0, 0.0, 0.0};
-    double fr = 0.0, gr = 0.0, lf = 0.0, lg = 0.0, rf = 0.0, rg = 0.0;
-    int leaf = 0, left_in_leaf = pl.len0 >> 3;            // wave-uniform cursor
-    auto fold = [&](int k) {
-        const bool left = pl.lsplit ? (k < 2) : (k < 1);
-        const bool first = pl.lsplit ? (k == 0 || k == 2) : (k <= 1);
-        if (left) { if (first) { lf = fr; lg = gr; } else { lf = lf + fr; lg = lg + gr; } }
-        else      { if (first) { rf = fr; rg = gr; } else { rf = rf + fr; rg = rg + gr; } }
-    };
-    auto consume = [&](const float (&x)[4], int r0) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const float xs = in(r0 + 4 * h + a) ? x[a] : 0.0f;
-            f[a] += (double)x[a];
-            g[a] += (double)xs;
-        }
-        if (--left_in_leaf == 0) {
-            const double tf = (f[0] + f[1]) + (f[2] + f[3]), tg = (g[0] + g[1]) + (g[2] + g[3]);
-            const double of = __shfl_xor(tf, 1), og = __shfl_xor(tg, 1);
-            fr = h == 0 ? tf + of : of + tf;          // (r0..r3) + (r4..r7), the same bits in both lanes
-            gr = h == 0 ? tg + og : og + tg;
-#pragma unroll
-            for (int a = 0; a < 4; a++) { f[a] = 0.0; g[a] = 0.0; }
-            if (!(leaf == pl.n_leaves - 1 && tail > 0)) fold(leaf);
-            leaf += 1;
-            left_in_leaf = ((leaf == 1) * pl.len1 + (leaf == 2) * pl.len2 + (leaf == 3) * pl.len3) >> 3;
-        }
-    };
-#pragma unroll 1
-    for (int gi = 0; gi < G; gi += 6) {
-#pragma unroll
-        for (int d = 0; d < 6; d++) {
-            if (gi + d < G) {
-                consume(st.q[d], (gi + d) * 8);
-                if (gi + d + 6 < G) st.load(st.q[d], (gi + d + 6) * 8);
-            }
-        }
-    }
-    if (tail > 0) {
-        if (G == 0) { fr = 0.0; gr = 0.0; }                  // n < 8: numpy's plain loop from 0.0
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            if (j < tail) {
-                const float xs = in(G * 8 + j) ? st.tl[j] : 0.0f;
-                fr += (double)st.tl[j];
-                gr += (double)xs;
-            }
-        }
-        fold(pl.n_leaves - 1);
     }
     if (pl.n_leaves == 1) { full = lf; part = lg; return; }
     full = lf + rf; part = lg + rg;
@@ -404,64 +292,44 @@ DEVFN void row_sums2(SeStream2 &st, int R, int h, InFn in, double &full, double 
 #endif
 
 // =============================================================================================
-// Allocation (kernel 1/2, or the first phase of the fused step kernel): one workgroup = one env,
-// thread = (slice s = slot / 16, UE position = slot % 16).
+// Kernel 1/2  alloc: one workgroup = one env, thread = slot (slice s = tid / 16, UE position tid % 16),
+// blockDim.x = S*16 rounded up to a wave.
 //   Policy  MARR agents/marr.py:40-47, MAPF agents/mapf.py:41-111
 //   Inter   IBSched.action_format agents/ib_sched.py:240-269, scores_to_rbs / round_int_equal_sum
 //           agents/common.py:442-505          (threads 0..15, one per slice)
 //   Intra   round_robin agents/common.py:508-555, proportional_fairness :558-636,
 //           max_throughput :639-701, distribute_rbs_ues :464-478   (16 lanes per slice)
+// Lanes that exchange data through LDS always sit in one wave (threads 0..15 for the inter-slice
+// part, the 16 lanes of a slice for the intra-slice part), so an LDS wait orders them; only the two
+// hand-overs between the parts need a workgroup barrier.
+// Results: rb_start / rb_count by UE (UEs outside every slice keep the 0 written at reset) and
+// policy_scores by slice.
 // =============================================================================================
 constexpr int ALLOC_NT = GRP * GRP;   // 256
 
 struct SharedAlloc {
     double xs[4][GRP];            // cross-slice rows
-    double rows[GRP + 1][2][GRP]; // per-slice rows (+ one row shared by slots past the grid: zeros only)
+    double rows[GRP][2][GRP];     // per-slice rows
     int rbs[GRP], off[GRP];
 };
 
-// The allocation of one env by the whole workgroup.  Slot k = (slice k / 16, UE position k % 16); the
-// S*16 slots are covered in NPASS passes of blockDim.x slots (blockDim.x a multiple of 64, so a slice's
-// 16 lanes never straddle a wave).  Lanes that exchange data through LDS always sit in one wave
-// (threads 0..15 for the inter-slice part, the 16 lanes of a slice for the intra-slice part), so an
-// LDS wait orders them; only the two hand-overs between the parts need a workgroup barrier.
-// Results go to rb_start / rb_count by UE in HBM and, when lds_start != nullptr, to those LDS arrays
-// too (the caller zeroes them and adds the barrier before reading).
-template <int NPASS>
-DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen, int *lds_start, int *lds_count)
+// The slot's inputs: UE id (-1 = empty slot), UEs of the slice, queue length, buffer size, packet
+// size, packets sent in the window, mean SE; hlen = pushes in the window.
+DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
+                       int ue, int n, int q, int mp, int pk, long long wsent, double sem)
 {
     auto &xs = sa.xs; auto &rows = sa.rows;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    const int tid = threadIdx.x, nthr = (int)blockDim.x;
-    const int pos = tid % GRP;
+    const int tid = threadIdx.x;
+    const int s = tid / GRP, pos = tid % GRP;
     const int S = p.S, U = p.U;
-    const int NS16 = S * GRP;
     const int gsh = (tid & 63) & ~(GRP - 1);
     const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
-
-    // ---- this thread's UEs: slot-ordered records (coalesced, one level) ---------------------------
-    int ue[NPASS], q[NPASS], mp[NPASS], pk[NPASS], nn[NPASS]; long long wsent[NPASS]; double sem[NPASS];
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ps++) {
-        const int slot = ps * nthr + tid;
-        ue[ps] = -1; q[ps] = 0; mp[ps] = 1; pk[ps] = 1; wsent[ps] = 0; sem[ps] = 0.0;
-        if (slot < NS16) {
-            const size_t ts = (size_t)sc * NS16 + slot, es = (size_t)e * NS16 + slot;
-            ue[ps] = p.tab.slot_ue[ts]; mp[ps] = p.tab.slot_mp[ts]; pk[ps] = p.tab.slot_pk[ts];
-            q[ps] = p.st.slot_q[es]; wsent[ps] = p.st.slot_ws[es]; sem[ps] = p.st.slot_sem[es];
-        }
-    }
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ps++) {
-        const int s = (ps * nthr + tid) / GRP;
-        const bool have = ue[ps] >= 0;
-        nn[ps] = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));   // UEs of this slice
-        if (mapf && s < GRP) {
-            const double occ = (double)q[ps] / (double)mp[ps];
-            const double hm = hlen > 0 ? (double)wsent[ps] / (double)hlen : 0.0;
-            rows[s][0][pos] = have ? occ : 0.0; rows[s][1][pos] = have ? hm : 0.0;
-        }
-    }
+    const bool have = ue >= 0;
+    double *ra = rows[s][0], *rb = rows[s][1];
+    const double occ = (double)q / (double)mp;
+    const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
+    if (mapf) { ra[pos] = have ? occ : 0.0; rb[pos] = have ? hm : 0.0; }
 
     // ---- inter role: thread t < 16 is slice t ---------------------------------------------------
     const int s1 = tid;
@@ -472,9 +340,6 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen, in
         active = si[0]; nues1 = si[2]; bsize = si[3]; msg = si[5]; sorted = si[7];
     }
     __syncthreads();
-#if RANENV_DIAG == 7
-    if (p.B > 0) { if (ok1) p.st.policy_scores[(size_t)e * S + s1] = rows[s1][0][0] + rows[s1][1][1]; return; }
-#endif
     if (tid < WAVE) {            // wave 0; the other waves go straight to the barrier below
         double score = -1.0;
         if (mapf) {
@@ -552,367 +417,122 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen, in
     __syncthreads();
 
     // ---- intra-slice: 16 lanes per slice ---------------------------------------------------------
+    const int n_rbs = s < S ? sa.rbs[s] : 0, off = s < S ? sa.off[s] : 0;
+    int choice = p.fixed_intra;
+    if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && s < S) ? (int)p.intra[(size_t)e * S + s] : RANENV_INTRA_RR;
+    const bool has_pkts = have && !d_isclose(occ, 0.0);
+    double avail = 0.0;                          // PF / MT path, evaluated by every slice
+    if (have) {
+        const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // :573-578
+        const double cap = sem * slice_bw / (double)n;
+        const double backlog = occ * (double)mp * (double)pk;
+        avail = cap < backlog ? cap : backlog;
+    }
+    ra[pos] = avail;
+    wave_sync();
+    double num = avail;                                                            // MT: weights = avail
+    if (choice == RANENV_INTRA_PF) {                                               // :584-602
+        double max_avail = ra[0];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ps++) {
-        const int slot_g = ps * nthr + tid;
-        const int s = slot_g / GRP;
-        const int sr = s < GRP ? s : GRP;          // slots past the grid share the spare row (zeros only)
-        double *ra = rows[sr][0], *rb = rows[sr][1];
-        const bool have = ue[ps] >= 0;
-        const int n = nn[ps];
-        const int n_rbs = s < S ? sa.rbs[s] : 0, off = s < S ? sa.off[s] : 0;
-        int choice = p.fixed_intra;
-        if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && s < S) ? (int)p.intra[(size_t)e * S + s] : RANENV_INTRA_RR;
-        const double occ = (double)q[ps] / (double)mp[ps];
-        const double hm = hlen > 0 ? (double)wsent[ps] / (double)hlen : 0.0;
-        const bool has_pkts = have && !d_isclose(occ, 0.0);
-        double avail = 0.0;                          // PF / MT path, evaluated by every slice
-        if (have) {
-            const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // :573-578
-            const double cap = sem[ps] * slice_bw / (double)n;
-            const double backlog = occ * (double)mp[ps] * (double)pk[ps];
-            avail = cap < backlog ? cap : backlog;
+        for (int k = 1; k < 16; k++) { const double av = ra[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+        double snt = hm * (double)pk;
+        if (d_isclose(avail, 0.0)) snt = 1.0;
+        num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
+    }
+    wave_sync();
+    rb[pos] = have ? num : 0.0;
+    wave_sync();
+    const double wsum = np_sum16_lds(rb, n);
+    const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
+    const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
+    const bool nzv = my_val != 0.0;
+    const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
+    const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
+    wave_sync();
+    ra[pos] = 0.0;
+    wave_sync();
+    if (nzv) ra[slot_v] = my_val;                                                  // compaction (:484-485)
+    rb[pos] = my_val;
+    wave_sync();
+    int count = 0;
+    if (use_round) {
+        const double tot = np_sum16_lds(ra, m_v);
+        const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
+        int acc = prop;
+#pragma unroll
+        for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+        const int adj = n_rbs - acc;
+        count = prop;
+        if (nzv && adj > 0) {
+            int rank = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { const double xk = rb[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+            count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
         }
-        ra[pos] = avail;
-        wave_sync();
-        double num = avail;                                                            // MT: weights = avail
-        if (choice == RANENV_INTRA_PF) {                                               // :584-602
-            double max_avail = ra[0];
-#pragma unroll
-            for (int k = 1; k < 16; k++) { const double av = ra[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
-            double snt = hm * (double)pk[ps];
-            if (d_isclose(avail, 0.0)) snt = 1.0;
-            num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
+    } else {
+        // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
+        const bool account = choice == RANENV_INTRA_RR;
+        const unsigned gmr = (unsigned)((__ballot(has_pkts && account) >> gsh) & 0xffffull);
+        int k_sel = __popc(gmr), idx = __popc(gmr & ((1u << pos) - 1u));
+        const bool all = (k_sel == 0);
+        if (all) { k_sel = n; idx = pos; }
+        if (have && (all || has_pkts) && k_sel > 0) {
+            const unsigned each = (unsigned)n_rbs / (unsigned)k_sel, rem = (unsigned)n_rbs - each * (unsigned)k_sel;
+            count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
-        wave_sync();
-        rb[pos] = have ? num : 0.0;
-        wave_sync();
-        const double wsum = np_sum16_lds(rb, n);
-        const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
-        const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
-        const bool nzv = my_val != 0.0;
-        const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
-        const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
-        wave_sync();
-        ra[pos] = 0.0;
-        wave_sync();
-        if (nzv) ra[slot_v] = my_val;                                                  // compaction (:484-485)
-        rb[pos] = my_val;
-        wave_sync();
-        int count = 0;
-        if (use_round) {
-            const double tot = np_sum16_lds(ra, m_v);
-            const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
-            int acc = prop;
+    }
+    int incl = count;                                                              // :464-478 contiguous ranges
 #pragma unroll
-            for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
-            const int adj = n_rbs - acc;
-            count = prop;
-            if (nzv && adj > 0) {
-                int rank = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k++) { const double xk = rb[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
-                count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
-            }
-        } else {
-            // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
-            const bool account = choice == RANENV_INTRA_RR;
-            const unsigned gmr = (unsigned)((__ballot(has_pkts && account) >> gsh) & 0xffffull);
-            int k_sel = __popc(gmr), idx = __popc(gmr & ((1u << pos) - 1u));
-            const bool all = (k_sel == 0);
-            if (all) { k_sel = n; idx = pos; }
-            if (have && (all || has_pkts) && k_sel > 0) {
-                const unsigned each = (unsigned)n_rbs / (unsigned)k_sel, rem = (unsigned)n_rbs - each * (unsigned)k_sel;
-                count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
-            }
-        }
-        int incl = count;                                                              // :464-478 contiguous ranges
-#pragma unroll
-        for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (pos >= d) ? v : 0; }
-        if (have) {
-            p.st.rb_start[(size_t)e * U + ue[ps]] = off + incl - count;
-            p.st.rb_count[(size_t)e * U + ue[ps]] = count;
-            if (lds_start) { lds_start[ue[ps]] = off + incl - count; lds_count[ue[ps]] = count; }
-        }
-        wave_sync();      // this pass's rows are read out before a later pass of the same wave reuses a row
+    for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (pos >= d) ? v : 0; }
+    if (have) {
+        p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
+        p.st.rb_count[(size_t)e * U + ue] = count;
     }
 }
+
 
 __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 {
     __shared__ SharedAlloc sa;
-    const int e = p.e0 + blockIdx.x;
+    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
 #if RANENV_DIAG == 6
     if (p.B > 0) return;       // launch cost only
 #endif
     const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
     const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
-    alloc_phase<1>(p, sa, e, sc, hlen, nullptr, nullptr);
-}
-
-// The same with 128 threads and two passes over the slots: two waves per workgroup instead of three
-// or four, so that all 16 workgroups a CU gets at the headline batch are resident at once (the kernel
-// is a chain of dependent steps; what it needs is more envs in flight, not more lanes per env).
-__global__ void __launch_bounds__(2 * WAVE) ranenv_alloc2_kernel(const KP p)
-{
-    __shared__ SharedAlloc sa;
-    const int e = p.e0 + blockIdx.x;
-    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
-    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
-    alloc_phase<2>(p, sa, e, sc, hlen, nullptr, nullptr);
-}
-
-// ---------------------------------------------------------------------------------------------
-// SE row reduction through LDS: groups of 8 RBs (8*U floats, contiguous in an RB-major tile) are
-// copied global -> LDS by 16-byte-per-lane loads that bypass the VGPRs (global_load_lds_dwordx4,
-// "LDS-DMA"); lane u then reads its 8 values of the group from LDS (consecutive UEs = consecutive
-// banks) and feeds numpy's 8 accumulators.  A ring of LDS_NB group buffers keeps LDS_NB-1 groups in
-// flight per workgroup without holding a single register; one raw s_barrier per group, the refill
-// of a buffer is issued one group after its last read.  Measured: 5.6-5.7 TB/s against 2.6 TB/s for
-// one dword per lane and RB (tools/bw_probe.hip).  Needs 16-byte aligned tiles; otherwise the
-// dword stream (SeStream) is used.
-// ---------------------------------------------------------------------------------------------
-#ifndef RANENV_LDS_NB
-#define RANENV_LDS_NB 4
-#endif
-constexpr int LDS_NB = RANENV_LDS_NB;
-
-template <typename InFn>
-DEVFN void row_sums_lds(unsigned char *ring, const float *tile, int U, int R, int u, InFn in, double &full, double &part)
-{
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int span = (int)blockDim.x * 16;         // bytes one instruction of the whole workgroup copies
-    const int CB = 32 * U;                         // bytes of one 8-RB group
-    const int tail = R & 7, G = R >> 3, NG = G + (tail ? 1 : 0);
-    const int ni = (CB + span - 1) / span;         // instructions per group (workgroup-uniform)
-    int niw = 0;                                   // ... of which this wave really issues (wave-uniform)
-    for (int k = 0; k < ni; k++) niw += (k * span + wave * 1024 < CB) ? 1 : 0;
-    auto issue = [&](int g) {
-        const int bytes = g < G ? CB : tail * 4 * U;
-        const char *src = (const char *)tile + (size_t)g * CB;
-        unsigned char *dst = ring + (g % LDS_NB) * CB;
-        for (int k = 0; k < ni; k++) {
-            const int wbase = k * span + wave * 1024;
-            if (wbase < CB) {                      // same test as niw (wave-uniform)
-                const int off = wbase + lane * 16;
-                if (off < bytes)                   // lanes past the chunk neither read nor write
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
-                                                     (__attribute__((address_space(3))) void *)(dst + wbase), 16, 0, 0);
-            }
-        }
-    };
-    auto wait_group = [&](bool steady) {
-        // all but the (LDS_NB-2) youngest groups of this wave have landed
-        if (!steady || niw == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (niw == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LDS_NB - 2) * 1) : "memory");
-        else if (niw == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LDS_NB - 2) * 2) : "memory");
-        else if (niw == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LDS_NB - 2) * 3) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    for (int g = 0; g < LDS_NB - 1; g++) if (g < NG) issue(g);
-
-    const RowPlan pl = make_row_plan(R);
-    double f[8], g8[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { f[j] = 0.0; g8[j] = 0.0; }
-    double fr = 0.0, gr = 0.0, lf = 0.0, lg = 0.0, rf = 0.0, rg = 0.0;
-    int leaf = 0, left_in_leaf = pl.len0 >> 3;            // workgroup-uniform cursor
-    auto fold = [&](int k) {
-        const bool left = pl.lsplit ? (k < 2) : (k < 1);
-        const bool first = pl.lsplit ? (k == 0 || k == 2) : (k <= 1);
-        if (left) { if (first) { lf = fr; lg = gr; } else { lf = lf + fr; lg = lg + gr; } }
-        else      { if (first) { rf = fr; rg = gr; } else { rf = rf + fr; rg = rg + gr; } }
-    };
-    for (int g = 0; g < NG; g++) {
-        wait_group(g + LDS_NB - 1 <= G);          // counted wait only while every younger group is a full one
-        __builtin_amdgcn_s_barrier();
-        if (g + LDS_NB - 1 < NG) issue(g + LDS_NB - 1);
-        const float *b = (const float *)(ring + (g % LDS_NB) * CB) + u;
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = (g < G || j < tail) ? b[j * U] : 0.0f;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads done before anyone refills this buffer
-        const int r0 = g * 8;
-        if (g < G) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float xs = in(r0 + j) ? x[j] : 0.0f;
-                f[j] += (double)x[j];
-                g8[j] += (double)xs;
-            }
-            if (--left_in_leaf == 0) {
-                fr = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-                gr = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
-#pragma unroll
-                for (int j = 0; j < 8; j++) { f[j] = 0.0; g8[j] = 0.0; }
-                if (!(leaf == pl.n_leaves - 1 && tail > 0)) fold(leaf);
-                leaf += 1;
-                left_in_leaf = ((leaf == 1) * pl.len1 + (leaf == 2) * pl.len2 + (leaf == 3) * pl.len3) >> 3;
-            }
-        } else {
-            if (G == 0) { fr = 0.0; gr = 0.0; }              // n < 8: numpy's plain loop from 0.0
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                if (j < tail) {
-                    const float xs = in(r0 + j) ? x[j] : 0.0f;
-                    fr += (double)x[j];
-                    gr += (double)xs;
-                }
-            }
-            fold(pl.n_leaves - 1);
-        }
+    // this thread's UE: slot tid of the env's slot-ordered records (coalesced, one level)
+    const int NS16 = p.S * GRP;
+    int ue = -1, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
+    if (tid < NS16) {
+        const size_t ts = (size_t)sc * NS16 + tid, es = (size_t)e * NS16 + tid;
+        ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; pk = p.tab.slot_pk[ts];
+        q = p.st.slot_q[es]; wsent = p.st.slot_ws[es]; sem = p.st.slot_sem[es];
     }
-    __builtin_amdgcn_s_barrier();     // the ring is free again (the caller may reuse LDS)
-    if (pl.n_leaves == 1) { full = lf; part = lg; return; }
-    full = lf + rf; part = lg + rg;
-}
-
-// ---------------------------------------------------------------------------------------------
-// SE row reduction, 16 B per lane: lane (c, j) of an env loads, for every group of 8 RBs, the float4
-// of RB 8g + j and UEs 4c..4c+3.  Lane j therefore IS numpy's accumulator j for those four UEs, and
-// the leaf result ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is an xor-butterfly over the 8 lanes of a quad.
-// A wave-level load covers eight 128-byte row segments; measured on MI355X this shape streams at
-// 5.3 TB/s where one dword per lane and row stops at 2.6 TB/s (tools/bw_probe.hip).
-// ---------------------------------------------------------------------------------------------
-constexpr int SE4_DEPTH = 4;
-
-struct SeStream4 {
-    float4 q[SE4_DEPTH];
-    __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile; out-of-range reads return 0
-    int U, c4, j;
-
-    DEVFN float4 load_row(int row)
-    {
-        const int off = (row * U + c4) * 4;     // per-lane byte offset: 17 loads per lane and TTI
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-        return __builtin_bit_cast(float4, v);
-    }
-    DEVFN void init(const float *tile, int U_, int c, int j_, int R)
-    {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U_ * R * 4, 0x00020000);
-        U = U_; c4 = 4 * c; j = j_;
-        const int G = R >> 3;
-#pragma unroll
-        for (int d = 0; d < SE4_DEPTH; d++) if (d < G) q[d] = load_row(d * 8 + j);
-    }
-};
-
-// full[k] / part[k] for the quad's UE k: sum over all RBs / over the RBs selected by in(k, r).
-// All 8 lanes of a quad return the same values.
-// SMALL: R <= 256, i.e. at most two leaves (left, right): four fewer register quads.
-template <bool SMALL, typename InFn>
-DEVFN void row_sums4(SeStream4 &st, int R, InFn in, double (&full)[4], double (&part)[4])
-{
-    const RowPlan pl = make_row_plan(R);
-    const int tail = R & 7, G = R >> 3, j = st.j;
-    double f[4] = {0.0, 0.0, 0.0, 0.0}, g[4] = {0.0, 0.0, 0.0, 0.0};
-    double fr[4] = {0.0, 0.0, 0.0, 0.0}, gr[4] = {0.0, 0.0, 0.0, 0.0};
-    double lf[4], lg[4], rf[SMALL ? 1 : 4], rg[SMALL ? 1 : 4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { lf[k] = lg[k] = 0.0; if (!SMALL) { rf[k] = rg[k] = 0.0; } }
-    int leaf = 0, left_in_leaf = pl.len0 >> 3;            // wave-uniform cursor
-    auto fold = [&](int lk) {
-        if (SMALL) {        // leaf 0 is the left half; leaf 1 (the right half) stays in fr/gr
-            if (lk == 0 && pl.n_leaves > 1) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { lf[k] = fr[k]; lg[k] = gr[k]; }
-            }
-            return;
-        }
-        const bool left = pl.lsplit ? (lk < 2) : (lk < 1);
-        const bool first = pl.lsplit ? (lk == 0 || lk == 2) : (lk <= 1);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (left) { if (first) { lf[k] = fr[k]; lg[k] = gr[k]; } else { lf[k] = lf[k] + fr[k]; lg[k] = lg[k] + gr[k]; } }
-            else      { if (first) { rf[k] = fr[k]; rg[k] = gr[k]; } else { rf[k] = rf[k] + fr[k]; rg[k] = rg[k] + gr[k]; } }
-        }
-    };
-    auto add_row = [&](const float4 &v, int row, double (&af)[4], double (&ag)[4]) {
-        const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float xs = in(k, row) ? x[k] : 0.0f;
-            af[k] += (double)x[k];
-            ag[k] += (double)xs;
-        }
-    };
-    auto consume = [&](const float4 &v, int g0) {
-        add_row(v, g0 * 8 + j, f, g);
-        if (--left_in_leaf == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {            // numpy's tree = xor-butterfly over the quad's 8 lanes
-                double a = f[k], b2 = g[k];
-                a += __shfl_xor(a, 1); b2 += __shfl_xor(b2, 1);
-                a += __shfl_xor(a, 2); b2 += __shfl_xor(b2, 2);
-                a += __shfl_xor(a, 4); b2 += __shfl_xor(b2, 4);
-                fr[k] = a; gr[k] = b2; f[k] = 0.0; g[k] = 0.0;
-            }
-            if (!(leaf == pl.n_leaves - 1 && tail > 0)) fold(leaf);
-            leaf += 1;
-            left_in_leaf = ((leaf == 1) * pl.len1 + (leaf == 2) * pl.len2 + (leaf == 3) * pl.len3) >> 3;
-        }
-    };
-#pragma unroll 1
-    for (int gi = 0; gi < G; gi += SE4_DEPTH) {
-#pragma unroll
-        for (int d = 0; d < SE4_DEPTH; d++) {
-            if (gi + d < G) {
-                consume(st.q[d], gi + d);
-                if (gi + d + SE4_DEPTH < G) st.q[d] = st.load_row((gi + d + SE4_DEPTH) * 8 + j);
-            }
-        }
-    }
-    if (tail > 0) {
-        if (G == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) { fr[k] = 0.0; gr[k] = 0.0; }   // n < 8: numpy's plain loop from 0.0
-        }
-        float4 tl[7];              // the tail rows are the same for the 8 lanes of a quad
-#pragma unroll
-        for (int t = 0; t < 7; t++) tl[t] = t < tail ? st.load_row(G * 8 + t) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < 7; t++) if (t < tail) add_row(tl[t], G * 8 + t, fr, gr);
-        fold(pl.n_leaves - 1);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (SMALL) {           // one leaf: the row sum is fr; two leaves: left + right
-            full[k] = pl.n_leaves == 1 ? fr[k] : lf[k] + fr[k];
-            part[k] = pl.n_leaves == 1 ? gr[k] : lg[k] + gr[k];
-        } else {
-            full[k] = pl.n_leaves == 1 ? lf[k] : lf[k] + rf[k];
-            part[k] = pl.n_leaves == 1 ? lg[k] : lg[k] + rg[k];
-        }
-    }
+    const int gsh = (tid & 63) & ~(GRP - 1);
+    const int n = __popc((unsigned)((__ballot(ue >= 0) >> gsh) & 0xffffull));   // UEs of this slice
+    alloc_phase(p, sa, e, sc, hlen, ue, n, q, mp, pk, wsent, sem);
 }
 
 // =============================================================================================
 // Kernel 2/2  core: one workgroup = one env, three roles in sequence
-//   (1) stream   thread = (UE quad, RB mod 8): SE row sums, 16 B loads, no LDS until the hand-off
+//   (1) stream   thread = UE: SE row sums in numpy's pairwise order (SeStream / row_sums)
 //   (2) UE step  thread = UE: capacity -> UEs.step -> 10-TTI window -> intent drift
 //                (oracle/ranenv_oracle.c; agents/common.py:68-340); its state loads are issued at
 //                kernel entry and land under the stream
 //   (3) obs      thread = slice (sorted position), threads 0..15: calculate_slice_ue_obs
 //                agents/common.py:343-378, IBSched.obs_space_format agents/ib_sched.py:91-200,
-//                calculate_reward :206-221 + common.py:381-439, per-env bookkeeping
+//                calculate_reward :206-221 + common.py:381-439, per-env counters
 // =============================================================================================
 struct SharedCore {
-    double se_full[ALLOC_NT], se_part[ALLOC_NT];   // hand-off (1) -> (2), indexed by UE
-    double rows[GRP][4][GRP];                      // hand-off (2) -> (3): drift x3, mean SE by [slice][metric][pos]
+    double rows[GRP][4][GRP];     // hand-off (2) -> (3): drift x3, mean SE by [slice][metric][pos]
     double xr[3][GRP];
-    int cnt[GRP][GRP];                             // RBs of each slot
+    int cnt[GRP][GRP];            // RBs of each slot
 };
 
-// STREAM: 0 = lane = UE, one dword per RB; 1 = float4 quads; 2 = LDS-DMA staging (default when aligned)
-// FUSE: 0 = the allocation was made by ranenv_alloc_kernel; 1 / 2 = this kernel makes it first, in that
-//       many passes of blockDim.x slots (MODE_STEP with STREAM 0 only)
-template <int MODE, bool SMALL, int STREAM, int FUSE = 0>
+template <int MODE>
 __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 {
-    constexpr bool QUADS = STREAM == 1;
-    static_assert(FUSE == 0 || (MODE == MODE_STEP && STREAM == 0), "fused allocation: step mode, dword stream");
     __shared__ SharedCore sh;
-    extern __shared__ __align__(16) unsigned char dyn_ring[];
     auto &rows = sh.rows; auto &xr = sh.xr;
     const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
@@ -944,67 +564,30 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     else tile = p.se_pool + (size_t)(ep.se_base + (long long)se_pos) * (size_t)p.se_stride;
 
     // ---- (1) stream role: issue the SE loads first ------------------------------------------------
-    const int C = (U + 3) >> 2;
-    const int qc = tid >> 3, qj = tid & 7;
-    const bool sact = qc < C;
-    SeStream4 se;
     SeStream se1;
-    unsigned ust[4] = {0, 0, 0, 0}, ucn[4] = {0, 0, 0, 0};
-    if (QUADS) {
-        se.init(tile, U, sact ? qc : C - 1, qj, R);
-        if (MODE == MODE_STEP) {   // RB ranges of the quad's UEs (0 for UEs outside every slice: zeroed at reset)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int uq = se.c4 + k;
-                if (uq < U) { ust[k] = (unsigned)p.st.rb_start[(size_t)e * U + uq]; ucn[k] = (unsigned)p.st.rb_count[(size_t)e * U + uq]; }
-            }
-        }
-    } else if (STREAM == 0) {
-        se1.init(tile, U, tid < U ? tid : U - 1, R);   // lane = UE: one dword per RB
-    }
+    se1.init(tile, U, tid < U ? tid : U - 1, R);   // lane = UE: one dword per RB
 
-    // ---- (0) fused allocation: the SE loads above are in flight while the RBs are handed out ----
-    if constexpr (FUSE > 0) {
-        __shared__ SharedAlloc sa;
-        int *a_start = &sh.cnt[0][0], *a_count = reinterpret_cast<int *>(&sh.se_full[0]);   // free until (2)
-        for (int i = tid; i < ALLOC_NT; i += (int)blockDim.x) { a_start[i] = 0; a_count[i] = 0; }
-        alloc_phase<FUSE>(p, sa, e, sc, hlen, a_start, a_count);
-        __syncthreads();
-    }
-
-    // ---- (2) UE role: only the RB range is needed by the stream; the rest of the UE's state is loaded
-    //      after it, so that the stream (24 loads + 16 double accumulators per lane) runs in few enough
-    //      registers for more workgroups per CU
+    // ---- (2) UE role: everything this UE needs, issued now so that it lands under the stream -----
     const bool act = tid < U;
     const int u = act ? tid : U - 1;
     const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
-    int rb_start = 0, rb_count = 0;
-    if (MODE == MODE_STEP) {
-        if (FUSE > 0) { rb_start = sh.cnt[0][u]; rb_count = reinterpret_cast<const int *>(&sh.se_full[0])[u]; __syncthreads(); }
-        else { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
-    }
-    // the rest of the UE's state: requested by load_state(), which the stream calls before its last turn
-    int slc = -1, ue_pos = 0, pkt_size = 1, max_pkts = 1, max_age = 0;
-    int total = 0, front = 0, front_rem = 0, fifo = 0;
+    const int slc = p.tab.ue_slice[tu], ue_pos = p.tab.ue_pos[tu];
+    const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
+    int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
+    if (MODE != MODE_RESET) {
+        total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
+        front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
+    }
+    if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
+    if (MODE == MODE_STEP) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
     int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
     int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
+    if (hlen == D) { old_s = *rs; old_d = *rd; }
     double traffic = 0.0;
-    auto load_state = [&]() {
-        slc = p.tab.ue_slice[tu]; ue_pos = p.tab.ue_pos[tu];
-        pkt_size = p.tab.ue_pkt_size[tu]; max_pkts = p.tab.ue_max_pkts[tu]; max_age = p.tab.ue_max_age[tu];
-        if (MODE != MODE_RESET) {
-            total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
-            front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
-        }
-        if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
-        if (hlen == D) { old_s = *rs; old_d = *rd; }
-        if (MODE != MODE_RESET)
-            traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
-    };
-    constexpr bool LATE_STATE = RANENV_LATE_STATE != 0 && STREAM == 0;
-    if (!LATE_STATE) load_state();
+    if (MODE != MODE_RESET)
+        traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
     // zero the (2) -> (3) rows
     for (int i = tid; i < GRP * 4 * GRP; i += (int)blockDim.x) (&rows[0][0][0])[i] = 0.0;
     for (int i = tid; i < GRP * GRP; i += (int)blockDim.x) (&sh.cnt[0][0])[i] = 0;
@@ -1012,52 +595,22 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     // ---- (1) SE row sums -------------------------------------------------------------------------
     RANENV_STAMP(1);
     double my_full = 0.0, my_part = 0.0;
-    if (QUADS) {
-        double sfull[4], spart[4];
-        if (MODE == MODE_STEP) {
-            row_sums4<SMALL>(se, R, [&](int k, int r) { return ((unsigned)r - ust[k]) < ucn[k]; }, sfull, spart);
-        } else if (MODE == MODE_DENSE) {
-            const uint8_t *mbase = p.dense + (size_t)e * U * R;
-            const int c4 = se.c4;
-            row_sums4<SMALL>(se, R, [&](int k, int r) { const int uq = c4 + k < U ? c4 + k : U - 1; return mbase[(size_t)uq * R + r] != 0; }, sfull, spart);
-        } else {
-            row_sums4<SMALL>(se, R, [](int, int) { return false; }, sfull, spart);
-        }
-        if (sact && qj == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (se.c4 + k < U) { sh.se_full[se.c4 + k] = sfull[k]; sh.se_part[se.c4 + k] = spart[k]; }
-        }
-        __syncthreads();
-        my_full = sh.se_full[u]; my_part = sh.se_part[u];
-    } else if (STREAM == 2) {
-        unsigned char *ring = (unsigned char *)(((size_t)dyn_ring + 15) & ~(size_t)15);
-        if (MODE == MODE_STEP) {
-            const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
-            row_sums_lds(ring, tile, U, R, u, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part);
-        } else if (MODE == MODE_DENSE) {
-            const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-            row_sums_lds(ring, tile, U, R, u, [=](int r) { return mrow[r] != 0; }, my_full, my_part);
-        } else {
-            row_sums_lds(ring, tile, U, R, u, [](int) { return false; }, my_full, my_part);
-        }
-    } else {
-        if (MODE == MODE_STEP) {
-            const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
+    if (MODE == MODE_STEP) {
+        const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1
-            my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
+        my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
 #elif RANENV_DIAG == 2
-            row_sums(se1, R, [=](int r) { return false; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part); my_part = (double)(us1 + uc1);
+        row_sums(se1, R, [=](int r) { return false; }, my_full, my_part); my_part = (double)(us1 + uc1);
 #else
-            row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part);
+        row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part);
 #endif
-        } else if (MODE == MODE_DENSE) {
-            const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-            row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part);
-        } else {
-            row_sums(se1, R, [](int) { return false; }, [&]() { if (LATE_STATE) load_state(); }, my_full, my_part);
-        }
-        __syncthreads();        // the (2) -> (3) rows were zeroed above by all threads
+    } else if (MODE == MODE_DENSE) {
+        const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
+        row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part);
+    } else {
+        row_sums(se1, R, [](int) { return false; }, my_full, my_part);
     }
+    __syncthreads();        // the (2) -> (3) rows were zeroed above by all threads
 
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
     RANENV_STAMP(2);
@@ -1334,25 +887,9 @@ struct ranenv {
     ranenv_episode *d_episodes = nullptr;
     bool have_scenarios = false, have_episodes = false;
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
-    int nt = 0, lds_bytes = 0;
-    // the batch is stepped as n_chunks independent sub-batches on parallel streams, so that the
-    // latency-bound alloc/obs kernels of one chunk overlap the bandwidth-bound core kernel of another
-    static constexpr int MAX_CHUNKS = 16;
-    int n_chunks = 1;
-    hipStream_t aux[MAX_CHUNKS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_CHUNKS] = {};
-    hipStream_t main_stream = nullptr;          // used when the caller hands over the null stream,
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // which cannot be captured
-    // replay cache: a launch sequence whose arguments repeat is captured once into a hipGraph
-    struct Cached { bool used = false; int mode = -1; int seen = 0; KP kp; hipGraphExec_t exec = nullptr; };
-    Cached cache[6];
-    int cache_next = 0;
-    bool use_graph = true;
-    bool alloc2 = false;                // alloc kernel with 128 threads and two slot passes (RANENV_ALLOC2=1)
-    bool fuse = false;                  // allocation fused into the step kernel (RANENV_FUSE=1; default: two kernels)
-    bool quads = false;                 // core variant: float4 quads (RANENV_QUADS=1)
-    bool lds_dma = false;               // core variant: LDS-DMA staged SE stream (RANENV_LDS_DMA=1 enables)
-    bool prof_on = false;               // ranenv_step_profiled: events around each kernel
+    int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
+    int nslot = 0;                              // threads of the alloc kernel (one per slot, whole waves)
+    bool prof_on = false;                       // ranenv_step_profiled: events around each kernel
     hipEvent_t prof_ev[3] = {};
     std::string err;
 };
@@ -1392,131 +929,19 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
     return RANENV_OK;
 }
 
-// One TTI of envs [e0, e0 + n_env) = alloc -> core on one stream (reset / dense skip alloc).
+// One TTI of the whole batch on the caller's stream: alloc -> core (reset / dense skip alloc).
 template <int MODE>
-void launch_chunk(ranenv_handle h, KP kp, int e0, int n_env, hipStream_t stream)
+hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream)
 {
-    kp.e0 = e0;
-    const dim3 sblock((unsigned)(((kp.S * GRP) + WAVE - 1) / WAVE * WAVE));   // one thread per slot
-    const dim3 cblock((unsigned)h->nt);
+    kp.e0 = 0;
+    const dim3 grid((unsigned)kp.B);
     hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;       // diagnostic per-kernel timing
-    // LDS-DMA needs 16-byte aligned tiles: pool base, tile stride and (for explicit tiles) U*R*4
-    const float *tiles = kp.se_tiles ? kp.se_tiles : kp.se_pool;
-    const long long tstride = kp.se_tiles ? (long long)kp.U * kp.R : kp.se_stride;
-    const bool aligned = (((size_t)tiles) & 15) == 0 && (tstride & 3) == 0;
-    const bool use_lds = h->lds_dma && aligned;
-    // One kernel per TTI: the allocation is the first phase of the step kernel (>= 128 threads, so that
-    // the S*16 slots take at most two passes)
-    const bool fuse = MODE == MODE_STEP && h->fuse && !h->quads && !use_lds;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    if (MODE == MODE_STEP && !fuse) {
-        if (h->alloc2 && kp.S * GRP > 2 * WAVE) hipLaunchKernelGGL(ranenv_alloc2_kernel, dim3(n_env), dim3(2 * WAVE), 0, stream, kp);
-        else hipLaunchKernelGGL(ranenv_alloc_kernel, dim3(n_env), sblock, 0, stream, kp);
-    }
+    if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[1], stream);
-    if (fuse) {
-        if constexpr (MODE == MODE_STEP) {
-            const dim3 fblock((unsigned)(h->nt < 2 * WAVE ? 2 * WAVE : h->nt));
-            if (kp.S * GRP > (int)fblock.x) hipLaunchKernelGGL((ranenv_core_kernel<MODE_STEP, false, 0, 2>), dim3(n_env), fblock, 0, stream, kp);
-            else hipLaunchKernelGGL((ranenv_core_kernel<MODE_STEP, false, 0, 1>), dim3(n_env), fblock, 0, stream, kp);
-        }
-    } else if (h->quads) {
-        if (kp.R <= 256) hipLaunchKernelGGL((ranenv_core_kernel<MODE, true, 1>), dim3(n_env), cblock, 0, stream, kp);
-        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 1>), dim3(n_env), cblock, 0, stream, kp);
-    } else if (use_lds) {
-        const size_t ring = (size_t)LDS_NB * 32 * kp.U + 16;
-        hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 2>), dim3(n_env), cblock, ring, stream, kp);
-    } else {
-        hipLaunchKernelGGL((ranenv_core_kernel<MODE, false, 0>), dim3(n_env), cblock, 0, stream, kp);
-    }
+    hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[2], stream);
-}
-
-// Fork the caller's stream into the chunk streams and join them back.
-template <int MODE>
-hipError_t enqueue(ranenv_handle h, const KP &kp, hipStream_t stream)
-{
-    const int nc = h->n_chunks;
-    if (nc <= 1) {
-        launch_chunk<MODE>(h, kp, 0, kp.B, stream);
-        return hipGetLastError();
-    }
-    hipError_t e = hipEventRecord(h->ev_fork, stream);
-    if (e != hipSuccess) return e;
-    const int per = (kp.B + nc - 1) / nc;
-    for (int c = 0; c < nc; c++) {
-        const int e0 = c * per, n_env = (e0 + per <= kp.B) ? per : kp.B - e0;
-        if (n_env <= 0) break;
-        e = hipStreamWaitEvent(h->aux[c], h->ev_fork, 0);
-        if (e != hipSuccess) return e;
-        launch_chunk<MODE>(h, kp, e0, n_env, h->aux[c]);
-        e = hipEventRecord(h->ev_join[c], h->aux[c]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_join[c], 0);
-        if (e != hipSuccess) return e;
-    }
     return hipGetLastError();
-}
-
-// Launch with replay: the second time an identical argument block shows up, the sequence is
-// captured into a hipGraph; from then on it is replayed with one hipGraphLaunch.
-template <int MODE>
-hipError_t launch_on(ranenv_handle h, const KP &kp, hipStream_t stream);
-
-template <int MODE>
-hipError_t launch(ranenv_handle h, const KP &kp, hipStream_t stream)
-{
-    if (stream != nullptr || !h->use_graph || h->main_stream == nullptr) return launch_on<MODE>(h, kp, stream);
-    // the legacy null stream cannot be captured: run on the handle's own stream, ordered after the
-    // caller's earlier work and before its later work
-    hipError_t e = hipEventRecord(h->ev_in, stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(h->main_stream, h->ev_in, 0);
-    if (e == hipSuccess) e = launch_on<MODE>(h, kp, h->main_stream);
-    if (e == hipSuccess) e = hipEventRecord(h->ev_out, h->main_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->ev_out, 0);
-    return e;
-}
-
-template <int MODE>
-hipError_t launch_on(ranenv_handle h, const KP &kp, hipStream_t stream)
-{
-    if (!h->use_graph) return enqueue<MODE>(h, kp, stream);
-    ranenv::Cached *hit = nullptr;
-    for (auto &c : h->cache)
-        if (c.used && c.mode == MODE && memcmp(&c.kp, &kp, sizeof(KP)) == 0) { hit = &c; break; }
-    if (hit && hit->exec) return hipGraphLaunch(hit->exec, stream);
-    if (!hit) {   // first sighting: remember it, launch directly
-        ranenv::Cached &c = h->cache[h->cache_next];
-        h->cache_next = (h->cache_next + 1) % (int)(sizeof(h->cache) / sizeof(h->cache[0]));
-        if (c.exec) { (void)hipGraphExecDestroy(c.exec); c.exec = nullptr; }
-        c.used = true; c.mode = MODE; c.seen = 1; memcpy(&c.kp, &kp, sizeof(KP));
-        return enqueue<MODE>(h, kp, stream);
-    }
-    // second sighting: capture
-    hipGraph_t graph = nullptr;
-    const bool dbg = getenv("RANENV_DEBUG") != nullptr;
-    hipError_t e = hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) {
-        if (dbg) fprintf(stderr, "[ranenv] begin capture: %s\n", hipGetErrorString(e));
-        h->use_graph = false; (void)hipGetLastError(); return enqueue<MODE>(h, kp, stream);
-    }
-    hipError_t e1 = enqueue<MODE>(h, kp, stream);
-    e = hipStreamEndCapture(stream, &graph);
-    if (e1 != hipSuccess || e != hipSuccess || graph == nullptr) {
-        if (dbg) fprintf(stderr, "[ranenv] capture failed: enqueue=%s end=%s\n", hipGetErrorString(e1), hipGetErrorString(e));
-        h->use_graph = false; (void)hipGetLastError();
-        if (graph) (void)hipGraphDestroy(graph);
-        return enqueue<MODE>(h, kp, stream);
-    }
-    hipGraphExec_t exec = nullptr;
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess || exec == nullptr) {
-        if (dbg) fprintf(stderr, "[ranenv] instantiate: %s\n", hipGetErrorString(e));
-        h->use_graph = false; (void)hipGetLastError(); return enqueue<MODE>(h, kp, stream);
-    }
-    if (dbg) fprintf(stderr, "[ranenv] graph captured for mode %d\n", MODE);
-    hit->exec = exec;
-    return hipGraphLaunch(exec, stream);
 }
 
 }  // namespace
@@ -1564,7 +989,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.tab.ue_max_pkts, NS * U); ALLOC(kp.tab.ue_max_age, NS * U);
     ALLOC(kp.st.queue_pkts, B * U); ALLOC(kp.st.queue_age_sum, B * U); ALLOC(kp.st.front, B * U);
     ALLOC(kp.st.front_rem, B * U); ALLOC(kp.st.fifo, B * U); ALLOC(kp.st.win_sent, B * U); ALLOC(kp.st.win_dropped, B * U);
-    ALLOC(kp.st.se_mean, B * U); ALLOC(kp.st.se_part, B * U);
+    ALLOC(kp.st.se_mean, B * U);
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
     ALLOC(kp.st.hist_len, B); ALLOC(kp.st.n_push, B); ALLOC(kp.st.step_no, B);
     ALLOC(kp.st.se_pos, B); ALLOC(kp.st.trf_pos, B);
@@ -1575,55 +1000,19 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         const size_t NSL = (size_t)S * GRP;
         ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
         ALLOC(kp.st.slot_q, B * NSL); ALLOC(kp.st.slot_ws, B * NSL); ALLOC(kp.st.slot_sem, B * NSL);
-        ALLOC(kp.st.slot_d0, B * NSL); ALLOC(kp.st.slot_d1, B * NSL); ALLOC(kp.st.slot_d2, B * NSL);
-        ALLOC(kp.st.slot_rbc, B * NSL);
     }
     ALLOC(h->d_episodes, B);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
-    {   // core workgroup: one lane per UE (or 8 lanes per UE quad with RANENV_QUADS=1), >= 16 slice lanes
-        const char *env_q = getenv("RANENV_QUADS");
-        h->quads = env_q && atoi(env_q) != 0;
-        const char *env_l = getenv("RANENV_LDS_DMA");
-        const char *env_a = getenv("RANENV_ALLOC2");
-        h->alloc2 = env_a ? atoi(env_a) != 0 : false;   // measured: 28 us against 26 us for one pass with 3 waves
-        const char *env_f = getenv("RANENV_FUSE");
-        h->fuse = env_f ? atoi(env_f) != 0 : false;   // measured: 102 us fused vs 99 us as two kernels
-        h->lds_dma = env_l && atoi(env_l) != 0;   // opt-in: measured slower when fused (its in-flight data competes for LDS)
-        const int need = h->quads ? (((U + 3) / 4) * 8 > U ? ((U + 3) / 4) * 8 : U) : U;
-        h->nt = (need + WAVE - 1) / WAVE * WAVE;
-        if (h->nt > ALLOC_NT) { ranenv_destroy(h); return fail(nullptr, RANENV_E_INVALID, "this build steps at most 256 UEs per env"); }
-    }
-    h->lds_bytes = GRP * 4 * GRP * 8 + 3 * GRP * 8;   // static LDS of the widest kernel (obs)
+    h->nt = (U + WAVE - 1) / WAVE * WAVE;               // core kernel: one lane per UE, at least the 16 slice lanes
+    h->nslot = (S * GRP + WAVE - 1) / WAVE * WAVE;      // alloc kernel: one lane per slot
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
         e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_alloc_kernel));
         if (e != hipSuccess) {
             ranenv_destroy(h);
             return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
-        }
-    }
-    {
-        const char *env_c = getenv("RANENV_CHUNKS");
-        int nc = env_c ? atoi(env_c) : 1;   // measured on MI355X: event-joined chunk streams cost more than they hide
-        if (nc < 1) nc = 1;
-        if (nc > ranenv::MAX_CHUNKS) nc = ranenv::MAX_CHUNKS;
-        if (nc > cfg->batch) nc = cfg->batch;
-        h->n_chunks = nc;
-        const char *env_g = getenv("RANENV_GRAPH");
-        h->use_graph = env_g && atoi(env_g) != 0;   // opt-in: replay needs a capturable (non-null) stream to pay off
-        if (h->use_graph) {
-            HIP_TRY(h, hipStreamCreateWithFlags(&h->main_stream, hipStreamNonBlocking));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
-        }
-        if (nc > 1) {
-            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            for (int c = 0; c < nc; c++) {
-                HIP_TRY(h, hipStreamCreateWithFlags(&h->aux[c], hipStreamNonBlocking));
-                HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join[c], hipEventDisableTiming));
-            }
         }
     }
     *out = h;
@@ -1635,16 +1024,7 @@ int ranenv_destroy(ranenv_handle h)
     if (!h) return RANENV_OK;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (auto &c : h->cache) if (c.exec) (void)hipGraphExecDestroy(c.exec);
-    for (int c = 0; c < ranenv::MAX_CHUNKS; c++) {
-        if (h->aux[c]) (void)hipStreamDestroy(h->aux[c]);
-        if (h->ev_join[c]) (void)hipEventDestroy(h->ev_join[c]);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
-    if (h->main_stream) (void)hipStreamDestroy(h->main_stream);
-    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
     return RANENV_OK;
@@ -1850,9 +1230,9 @@ int ranenv_step_profiled(ranenv_handle h, float *ms3, void *stream_)
     kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
     kp.dense = nullptr; kp.obs_inter = nullptr; kp.obs_intra = nullptr; kp.reward = nullptr; kp.done = nullptr;
     h->prof_on = true;
-    launch_chunk<MODE_STEP>(h, kp, 0, kp.B, stream);
+    const hipError_t le = launch<MODE_STEP>(h, kp, stream);
     h->prof_on = false;
-    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, le);
     HIP_TRY(h, hipEventSynchronize(h->prof_ev[2]));
     for (int k = 0; k < 2; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
     return RANENV_OK;
@@ -1877,7 +1257,7 @@ int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     if (grid) *grid = h->cfg.batch;
     if (block) *block = h->nt;
-    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    if (lds_bytes) *lds_bytes = (int32_t)sizeof(SharedCore);
     return RANENV_OK;
 }
 
