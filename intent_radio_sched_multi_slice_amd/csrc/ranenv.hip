@@ -19,8 +19,6 @@
 //                                          (oracle/ranenv_oracle.c) while a step touches only the
 //                                          inserted / expired / drained entries.
 //   10-TTI window  int32   [B][D][U] x2   pkt_effective_thr and dropped_pkts of the last D pushes
-//   slot records   [B][S*16]               queue length, window sum, mean SE in (slice, position) order:
-//                                          written by core, read coalesced by the next alloc
 //   scenario pool  small SoA tables, shared by all envs replaying a scenario (L2 resident)
 //
 // Reference behaviour restated here (file:line under lasseufpa/intent_radio_sched_multi_slice):
@@ -73,9 +71,6 @@ struct State {
     int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
     int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
-    // slot-ordered records, slot = slice*16 + position: written by the core kernel's UE lanes, read
-    // coalesced by the next TTI's alloc kernel                           [B][S*16]
-    int32_t *slot_q; int64_t *slot_ws; double *slot_sem;
 };
 
 struct KP {
@@ -500,13 +495,16 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
 #endif
     const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
     const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
-    // this thread's UE: slot tid of the env's slot-ordered records (coalesced, one level)
+    // this thread's UE: slot -> UE id from the scenario's slot table, then the UE's state
     const int NS16 = p.S * GRP;
     int ue = -1, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
     if (tid < NS16) {
-        const size_t ts = (size_t)sc * NS16 + tid, es = (size_t)e * NS16 + tid;
+        const size_t ts = (size_t)sc * NS16 + tid;
         ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; pk = p.tab.slot_pk[ts];
-        q = p.st.slot_q[es]; wsent = p.st.slot_ws[es]; sem = p.st.slot_sem[es];
+        if (ue >= 0) {
+            const size_t su = (size_t)e * p.U + ue;
+            q = p.st.queue_pkts[su]; wsent = p.st.win_sent[su]; sem = p.st.se_mean[su];
+        }
     }
     const int gsh = (tid & 63) & ~(GRP - 1);
     const int n = __popc((unsigned)((__ballot(ue >= 0) >> gsh) & 0xffffull));   // UEs of this slice
@@ -739,9 +737,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
 
         if (slc >= 0) {
-            // record for next TTI's alloc (slot-ordered) and rows for this TTI's observation
-            const size_t es = (size_t)e * (S * GRP) + slc * GRP + ue_pos;
-            p.st.slot_q[es] = total; p.st.slot_ws[es] = win_sent; p.st.slot_sem[es] = se_mean_new;
+            // rows for this TTI's observation
             rows[slc][0][ue_pos] = dres[0]; rows[slc][1][ue_pos] = dres[1]; rows[slc][2][ue_pos] = dres[2];
             rows[slc][3][ue_pos] = se_mean_new;
             sh.cnt[slc][ue_pos] = rb_count;
@@ -999,7 +995,6 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     {
         const size_t NSL = (size_t)S * GRP;
         ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
-        ALLOC(kp.st.slot_q, B * NSL); ALLOC(kp.st.slot_ws, B * NSL); ALLOC(kp.st.slot_sem, B * NSL);
     }
     ALLOC(h->d_episodes, B);
 #undef ALLOC
