@@ -1,0 +1,155 @@
+"""C-ABI behaviour besides the step arithmetic: config flags, the done flag, error reporting.
+
+All through BatchedRanEnv -> libranenv_hip.so on the GPU; the oracle is the checker.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from tests.common import poisson_traffic_rows
+from tests.synth import se_tile
+
+pytestmark = pytest.mark.gpu
+OBS_TOL, REW_TOL = 1e-5, 1e-9
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def _setup(flags=0, steps=12, B=4, seed=3):
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    S, U, R, G, Us = 5, 25, 135, 1, 5
+    tabs = generate_scaled_scenarios(3, seed=seed, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=3, min_ues=2)
+    rng = np.random.default_rng(seed)
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    se_pool = np.stack([se_tile(33, t, U, R) for t in range(B * steps)])
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
+    env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+                        n_scenarios=tabs.n_scenarios, max_steps=steps, flags=flags)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se_pool, -1, -2)), device=env.device))
+    env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
+    return env, tabs, scen, se_pool, trf, (S, U, R, G, Us)
+
+
+def _oracles(tabs, scen, dims, steps):
+    from oracle import pyoracle
+    S, U, R, G, Us = dims
+    cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+    out = []
+    for b in range(len(scen)):
+        o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, int(scen[b])); out.append(o)
+    return out
+
+
+def test_clear_history_on_reset_matches_a_fresh_env():
+    """RANENV_F_CLEAR_HISTORY_ON_RESET: after reset the 10-TTI window is empty, i.e. the env behaves like a
+    newly created one (the reference's deque is never cleared, agents/ib_sched.py:51; this flag is the opt-in)."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd import _lib
+    steps = 12
+    env, tabs, scen, se_pool, trf, dims = _setup(flags=_lib.F_CLEAR_HISTORY_ON_RESET, steps=steps)
+    S = dims[0]
+    env.set_policy(2, 1)
+    env.reset()
+    for _ in range(5):
+        env.step()
+    env.reset()
+    v = env.views()
+    assert int(v["hist_len"].max()) == 1 and int(v["win_sent"].abs().max()) == 0 and int(v["win_dropped"].abs().max()) == 0
+    oenvs = _oracles(tabs, scen, dims, steps)          # fresh oracles: empty deque
+    for b, o in enumerate(oenvs):
+        o.reset(se_pool[b * steps])
+    for t in range(6):
+        sc = np.stack([o.policy_mapf() for o in oenvs]); ic = np.ones((len(oenvs), S), dtype=np.uint8)
+        obs, rew, done = env.step()
+        for b, o in enumerate(oenvs):
+            o.step(sc[b], ic[b], se_pool[b * steps + t], trf[b * steps + t])
+            oo = o.obs()
+            np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=REW_TOL)
+    env.close()
+
+
+def test_no_raw_output_flag_only_skips_the_two_arrays():
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd import _lib
+    a, *_ = _setup(flags=0)
+    b, *_ = _setup(flags=_lib.F_NO_RAW_OUTPUT)
+    for env in (a, b):
+        env.set_policy(1, 0)
+        env.reset()
+    for _ in range(6):
+        oa, ra, _ = a.step()
+        ob, rb, _ = b.step()
+        assert torch.equal(oa["obs_inter"], ob["obs_inter"]) and torch.equal(oa["obs_intra"], ob["obs_intra"]) and torch.equal(ra, rb)
+    va, vb = a.views(), b.views()
+    for k in ("pkt_effective_thr", "dropped_pkts", "queue_pkts", "queue_age_sum", "rb_count"):
+        assert torch.equal(va[k], vb[k]), k
+    assert int(va["pkt_incoming"].abs().sum()) > 0 and int(vb["pkt_incoming"].abs().sum()) == 0
+    assert int(vb["pkt_throughputs"].abs().sum()) == 0
+    a.close(); b.close()
+
+
+def test_done_flag_and_step_counter():
+    _need_gpu()
+    steps = 5
+    env, *_ = _setup(steps=steps)
+    env.set_policy(1, 0)
+    env.reset()
+    for t in range(steps):
+        _, _, done = env.step()
+        assert int(env.views()["step_number"].min()) == t + 1
+        assert bool(done.all()) == (t + 1 >= steps)
+    env.reset()
+    assert int(env.views()["step_number"].max()) == 0
+    env.close()
+
+
+def test_errors_are_reported_not_swallowed():
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv, RanEnvError
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    with pytest.raises(RanEnvError, match="unsupported sizes"):
+        BatchedRanEnv(batch=1, n_slices=17, n_ues=10, n_rbs=20)
+    with pytest.raises(RanEnvError, match="unsupported sizes"):
+        BatchedRanEnv(batch=1, n_slices=4, n_ues=300, n_rbs=20, max_ues_slice=16)
+    env = BatchedRanEnv(batch=2, n_slices=3, n_ues=9, n_rbs=20, max_ues_slice=3, n_scenarios=1)
+    with pytest.raises(RanEnvError, match="no scenarios loaded"):
+        env.reset()
+    tabs = generate_scaled_scenarios(1, seed=1, n_slices=3, n_ues=9, max_ues_slice=3, min_slices=2, min_ues=1)
+    env.load_scenarios(tabs)
+    with pytest.raises(RanEnvError, match="no episode descriptors"):
+        env.reset()
+    with pytest.raises(RanEnvError, match="scenario 5 outside pool"):
+        env.set_episodes(scenario=np.array([0, 5]))
+    env.set_episodes(scenario=np.array([0, 0]))
+    with pytest.raises(RanEnvError, match="no SE tiles given and no SE pool bound"):
+        env.reset()
+    pool = torch.ones((4, 20, 9), dtype=torch.float32, device=env.device)
+    env.bind_se_pool(pool)
+    with pytest.raises(RanEnvError, match="exceeds the bound pool"):
+        env.set_episodes(scenario=np.array([0, 0]), se_base=np.array([0, 3]), se_len=2)
+    env.set_episodes(scenario=np.array([0, 0]), se_base=np.array([0, 2]), se_len=2)
+    env.reset()
+    with pytest.raises(RanEnvError, match="no traffic given and no traffic pool bound"):
+        env.step()
+    env.bind_traffic_pool(torch.zeros((2, 9), dtype=torch.int32, device=env.device))
+    env.set_episodes(scenario=np.array([0, 0]), se_base=np.array([0, 2]), se_len=2, trf_base=np.array([0, 1]), trf_len=1)
+    env.set_policy(0, 255)
+    with pytest.raises(RanEnvError, match="policy is EXTERNAL"):
+        env.step()
+    with pytest.raises(RanEnvError, match="expected shape"):
+        env.step(np.zeros((2, 4)), np.zeros((2, 3), dtype=np.uint8))
+    env.step(np.zeros((2, 3)), np.zeros((2, 3), dtype=np.uint8))     # and a good call still works
+    # a scenario row that is not self-consistent is refused at load time
+    import copy
+    broken = copy.deepcopy(tabs)
+    broken.sorted_slices[0, :] = 0
+    with pytest.raises(RanEnvError, match="not a permutation"):
+        env.load_scenarios(broken)
+    env.close()
