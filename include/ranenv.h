@@ -207,6 +207,16 @@ int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);
 
+/* Channel ingest: QuaDRiGa received power -> spectral efficiency, element by element,
+ *     se = float32( log2(1 + tx_power_per_rb * g / (0 + noise_power)) )            (float64 arithmetic)
+ * replaces QuadrigaChannel.step's per-TTI transform (channels/quadriga.py:56-69; tx_power_per_rb =
+ * transmission_power / num_available_rbs = 100 / R, noise_power = 10e-14, inter-cell interference 0).
+ * The per-step slice of target_cell_power is RB-major like the SE pool (:70-72 transposes it for the
+ * agents), so a power array [n][R][U] maps onto an SE pool [n][R][U] without a transpose.  Device
+ * pointers, n_elems elements; no handle (errors: ranenv_last_error(NULL)). */
+int ranenv_se_from_power(const double *dev_power, float *dev_se, int64_t n_elems,
+                         double tx_power_per_rb, double noise_power, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

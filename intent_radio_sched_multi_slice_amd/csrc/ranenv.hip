@@ -870,6 +870,28 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Channel ingest: received power -> spectral efficiency (channels/quadriga.py:56-69), elementwise.
+// 8 B read + 4 B written per element; two elements per thread and grid-stride, 16-byte loads.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ranenv_se_from_power_kernel(const double *power, float *se, long long n,
+                                                                   double tx_per_rb, double noise)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x * 2;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
+        if (i + 1 < n && ((size_t)(power + i) & 15) == 0 && ((size_t)(se + i) & 7) == 0) {
+            const double2 g = *reinterpret_cast<const double2 *>(power + i);
+            float2 o;
+            o.x = (float)log2(1.0 + (tx_per_rb * g.x) / (0.0 + noise));
+            o.y = (float)log2(1.0 + (tx_per_rb * g.y) / (0.0 + noise));
+            *reinterpret_cast<float2 *>(se + i) = o;
+        } else {
+            se[i] = (float)log2(1.0 + (tx_per_rb * power[i]) / (0.0 + noise));
+            if (i + 1 < n) se[i + 1] = (float)log2(1.0 + (tx_per_rb * power[i + 1]) / (0.0 + noise));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
@@ -1244,6 +1266,22 @@ int ranenv_get_views(ranenv_handle h, ranenv_views *out)
     out->win_sent = (int64_t *)s.win_sent; out->win_dropped = (int64_t *)s.win_dropped;
     out->step_number = s.step_no; out->hist_len = s.hist_len;
     out->mask_inter = s.mask_inter; out->mask_intra = s.mask_intra; out->policy_scores = s.policy_scores;
+    return RANENV_OK;
+}
+
+int ranenv_se_from_power(const double *dev_power, float *dev_se, int64_t n_elems, double tx_power_per_rb,
+                         double noise_power, void *stream)
+{
+    if (!dev_power || !dev_se) return fail(nullptr, RANENV_E_INVALID, "null argument");
+    if (n_elems < 0) return fail(nullptr, RANENV_E_INVALID, "negative element count");
+    if (!(noise_power > 0.0)) return fail(nullptr, RANENV_E_INVALID, "noise_power must be positive");
+    if (n_elems == 0) return RANENV_OK;
+    long long blocks = (n_elems + 511) / 512;
+    if (blocks > 256 * 64) blocks = 256 * 64;          // grid-stride beyond 64 workgroups per CU
+    hipLaunchKernelGGL(ranenv_se_from_power_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       dev_power, dev_se, (long long)n_elems, tx_power_per_rb, noise_power);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, RANENV_E_HIP, "se_from_power launch: %s", hipGetErrorString(e));
     return RANENV_OK;
 }
 

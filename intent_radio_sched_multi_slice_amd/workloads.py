@@ -48,6 +48,29 @@ def mimic_quadriga_pool(n_traces: int, trace_len: int, n_ues: int, n_rbs: int, s
     return pool
 
 
+def quadriga_pool_from_power(power: torch.Tensor, n_rbs: int, transmission_power: float = 100.0,
+                             thermal_noise_power: float = 10e-14) -> torch.Tensor:
+    """SE pool from QuaDRiGa received power (channels/quadriga.py:56-69), on the GPU.
+
+    ``power``: float64 [n_tiles, R, U] resident on a GPU -- the per-step slices of
+    ``target_cell_power`` in the .mat file's own RB-major order (the reference transposes them for the
+    agents, :70-72).  Returns the float32 [n_tiles, R, U] pool ``bind_se_pool`` takes.
+    """
+    import ctypes as C
+    from . import _lib
+    if not power.is_cuda or power.dtype != torch.float64 or power.dim() != 3 or power.shape[1] != n_rbs:
+        raise _lib.RanEnvError("power must be a float64 [n_tiles, R, U] tensor on the GPU")
+    power = power.contiguous()
+    out = torch.empty(power.shape, dtype=torch.float32, device=power.device)
+    lib = _lib.load()
+    with torch.cuda.device(power.device):
+        st = lib.ranenv_se_from_power(C.c_void_p(power.data_ptr()), C.c_void_p(out.data_ptr()), power.numel(),
+                                      float(transmission_power) / float(n_rbs), float(thermal_noise_power),
+                                      C.c_void_p(torch.cuda.current_stream(power.device).cuda_stream))
+    _lib.check(lib, None, st, "ranenv_se_from_power")
+    return out
+
+
 def poisson_traffic_pool(tables: ScenarioTables, trace_len: int, seed: int) -> np.ndarray:
     """[n_scenarios*trace_len, U] int32 offered bits: Poisson(slice Mbps) * 1e6 for the UEs of each
     slice (traffics/mult_slice.py:26-32); one trace per scenario."""

@@ -153,3 +153,23 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(RanEnvError, match="not a permutation"):
         env.load_scenarios(broken)
     env.close()
+
+
+def test_se_from_power_matches_the_reference_formula():
+    """Channel ingest kernel vs the expression of channels/quadriga.py:56-69 in numpy float64, stored float32.
+    log2 may differ from numpy's in the last float64 bit, so the float32 results are allowed to differ by one
+    float32 ulp in rare rounding ties; everything else must be identical."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.plugins import quadriga_se_from_power
+    from intent_radio_sched_multi_slice_amd.workloads import quadriga_pool_from_power
+    rng = np.random.default_rng(5)
+    for shape in ((7, 135, 100), (3, 25, 4), (1, 1, 1), (5, 33, 7)):
+        g = 10.0 ** rng.uniform(-16, -7, size=shape)            # received power per RB, W
+        g[0, 0, 0] = 0.0                                        # no signal -> SE 0
+        ref = quadriga_se_from_power(g, shape[1]).astype(np.float32)
+        got = quadriga_pool_from_power(torch.as_tensor(g, device="cuda"), shape[1]).cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == np.float32
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, ulp.max()
+        assert (ulp != 0).mean() <= 1e-3
+        assert got[0, 0, 0] == 0.0
