@@ -215,32 +215,55 @@ class SimpleAssociation(Association):
 
 
 class MultSliceAssociation(Association):
-    """associations/mult_slice.py generator mode (:359-423) plus update_ues (:468-488).
+    """associations/mult_slice.py: generator mode (:359-423), replay of ``ep_N.npz`` scenario files
+    (:424-442, :490-508; scenario = episode % 200, :444-452) and update_ues (:468-488).
 
-    The replay mode of the reference reads ``associations/data/mult_slice/ep_N.npz`` (pickled
-    dicts, absent from the snapshot); here a scenario is generated per episode from the same
-    generator law, consuming the shared rng in the reference's call order.
+    Replay reads ``{root_path}/associations/data/{scenario_name}/ep_{n}.npz`` (pickled dicts: trusted
+    files only).  In generator mode a scenario is drawn per episode from the same law, consuming the
+    shared rng in the reference's call order.
     """
 
     def __init__(self, ues, max_number_ues, max_number_basestations, max_number_slices, rng=None,
                  root_path: str = ".", generator_mode: bool = True, scenario_name: str = "mult_slice"):
         super().__init__(ues, max_number_ues, max_number_basestations, max_number_slices, rng, root_path)
         self.min_number_slices = 3
+        self.maximum_number_scenarios = 200
         self.generator_mode = generator_mode
+        self.scenario_name = scenario_name
         self.slice_types = [t[0] for t in SLICE_TEMPLATES]
         self.slice_type_model = {t[0]: slice_template_dict(i) for i, t in enumerate(SLICE_TEMPLATES)}
         self.slices_to_use = np.array([])
         self.current_episode = -1
+        self._ep = None
+
+    def choose_episode(self, episode_number: int, current_episode: int):
+        episode_to_use = episode_number % self.maximum_number_scenarios
+        if episode_to_use != current_episode:
+            return episode_to_use, True
+        return 0, False
+
+    def load_episode_data(self, episode_number: int):
+        from .scenario import load_episode_npz
+        self._ep = load_episode_npz(f"{self.root_path}/associations/data/{self.scenario_name}/ep_{episode_number}.npz")
+        self.current_episode = episode_number
 
     def step(self, basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req,
              step_number, episode_number):
-        if step_number == 0:
-            bua, bsa, sua, req, slices = generate_reference_scenario(
-                self.rng, self.max_number_slices, self.max_number_ues, self.min_number_slices)
-            self.slices_to_use = slices
-            self.update_ues(sua, slices, req)
-            return bua, bsa, sua, req
-        return basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req
+        if self.generator_mode:
+            if step_number == 0:
+                bua, bsa, sua, req, slices = generate_reference_scenario(
+                    self.rng, self.max_number_slices, self.max_number_ues, self.min_number_slices)
+                self.slices_to_use = slices
+                self.update_ues(sua, slices, req)
+                return bua, bsa, sua, req
+            return basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req
+        episode_to_use, condition = self.choose_episode(episode_number, self.current_episode)
+        if condition:
+            self.load_episode_data(episode_to_use)
+            self.update_ues(self._ep["hist_slice_ue_assoc"][step_number], self._ep["hist_slices_to_use"][step_number],
+                            self._ep["hist_slice_req"][step_number])
+        return (self._ep["hist_basestation_ue_assoc"][step_number], self._ep["hist_basestation_slice_assoc"][step_number],
+                self._ep["hist_slice_ue_assoc"][step_number], self._ep["hist_slice_req"][step_number])
 
     def update_ues(self, slice_ue_assoc, slices_to_use, slice_req):
         for s in slices_to_use:

@@ -371,3 +371,57 @@ def generate_scaled_scenarios(
             used += counts[k]
         t.set_from_reference(i, bsa, sua, req, enable_sort_slices)
     return t
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's scenario files (associations/data/{scenario}/ep_N.npz)
+# --------------------------------------------------------------------------------------------
+EPISODE_FILE_KEYS = ("hist_basestation_ue_assoc", "hist_basestation_slice_assoc", "hist_slice_ue_assoc",
+                     "hist_slice_req", "hist_slices_lifetime", "hist_slices_to_use")
+
+
+def save_episode_npz(path: str, basestation_ue_assoc: np.ndarray, basestation_slice_assoc: np.ndarray,
+                     slice_ue_assoc: np.ndarray, slice_req: dict, slices_to_use: np.ndarray, n_steps: int) -> None:
+    """Write one scenario in the schema of gen_assoc_mult_slice.py:229-237: per-step histories (the
+    scenario is constant over the episode, so the step-0 objects are repeated), dicts and ragged
+    arrays pickled inside object arrays."""
+    hist_req = np.empty(n_steps, dtype=object)
+    hist_use = np.empty(n_steps, dtype=object)
+    for t in range(n_steps):
+        hist_req[t] = slice_req
+        hist_use[t] = np.asarray(slices_to_use)
+    np.savez_compressed(
+        path,
+        hist_basestation_ue_assoc=np.repeat(np.asarray(basestation_ue_assoc)[None], n_steps, axis=0),
+        hist_basestation_slice_assoc=np.repeat(np.asarray(basestation_slice_assoc)[None], n_steps, axis=0),
+        hist_slice_ue_assoc=np.repeat(np.asarray(slice_ue_assoc)[None], n_steps, axis=0),
+        hist_slice_req=hist_req,
+        hist_slices_lifetime=np.zeros((n_steps, np.asarray(slice_ue_assoc).shape[0])),
+        hist_slices_to_use=hist_use,
+    )
+
+
+def load_episode_npz(path: str) -> Dict[str, np.ndarray]:
+    """Read a scenario file the way MultSliceAssociation.load_episode_data does
+    (associations/mult_slice.py:490-508).  The file holds pickled objects: only open files you trust."""
+    with np.load(path, allow_pickle=True, mmap_mode=None) as f:
+        missing = [k for k in EPISODE_FILE_KEYS if k not in f.files]
+        if missing:
+            raise ValueError(f"{path}: not a scenario file, missing {missing}")
+        return {k: f[k] for k in EPISODE_FILE_KEYS}
+
+
+def tables_from_episode_files(paths, n_slices: int, n_ues: int, max_ues_slice: int, step: int = 0,
+                              enable_sort_slices: bool = True) -> ScenarioTables:
+    """One scenario-pool row per ep_N.npz (its ``step``-th entry; mult_slice scenarios do not change
+    inside an episode) -- the ingest of SURVEY section 8f-1 for the association side."""
+    paths = list(paths)
+    tabs = ScenarioTables.empty(len(paths), n_slices, n_ues, max_ues_slice)
+    for i, path in enumerate(paths):
+        ep = load_episode_npz(path)
+        sua = np.asarray(ep["hist_slice_ue_assoc"][step], dtype=np.float64)
+        bsa = np.asarray(ep["hist_basestation_slice_assoc"][step], dtype=np.float64)
+        if sua.shape != (n_slices, n_ues):
+            raise ValueError(f"{path}: slice_ue_assoc is {sua.shape}, expected {(n_slices, n_ues)}")
+        tabs.set_from_reference(i, bsa, sua, ep["hist_slice_req"][step], enable_sort_slices)
+    return tabs

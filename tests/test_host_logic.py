@@ -168,3 +168,43 @@ def test_metrics_gather_world_size_2_gloo():
         assert summ["violations"] == 5                       # rank 0's five envs have negative reward
         assert summ["pkts_sent"] == 5 * 4 * 1 + 5 * 4 * 2
         assert np.isclose(summ["reward_inter_sum"], 5 * -0.5 + 5 * 0.25)
+
+
+def test_scenario_file_roundtrip_and_replay(tmp_path):
+    """ep_N.npz in the schema of gen_assoc_mult_slice.py:229-237: writer -> reader -> scenario tables equal
+    the tables made from the objects directly; MultSliceAssociation in replay mode serves them per step."""
+    from intent_radio_sched_multi_slice_amd.plugins import MultSliceAssociation, UEs
+    from intent_radio_sched_multi_slice_amd.scenario import (ScenarioTables, generate_reference_scenario,
+                                                           load_episode_npz, save_episode_npz,
+                                                           tables_from_episode_files)
+    S, U, Us = 5, 25, 5
+    root = tmp_path / "associations" / "data" / "mult_slice"
+    root.mkdir(parents=True)
+    direct = ScenarioTables.empty(3, S, U, Us)
+    objs = []
+    for n in range(3):
+        rng = np.random.default_rng(100 + n)
+        bua, bsa, sua, req, slices = generate_reference_scenario(rng, S, U, 3)
+        save_episode_npz(str(root / f"ep_{n}.npz"), bua, bsa, sua, req, slices, n_steps=4)
+        direct.set_from_reference(n, bsa, sua, req, True)
+        objs.append((bua, bsa, sua, req, slices))
+    ep = load_episode_npz(str(root / "ep_1.npz"))
+    assert ep["hist_slice_ue_assoc"].shape == (4, S, U) and ep["hist_slice_req"][2] == objs[1][3]
+    got = tables_from_episode_files([str(root / f"ep_{n}.npz") for n in range(3)], S, U, Us)
+    for k, a in direct.arrays().items():
+        assert np.array_equal(a, got.arrays()[k]), k
+    # replay mode of the association plugin (associations/mult_slice.py:424-442)
+    ues = UEs(U, np.repeat(1, U), np.repeat(1, U), np.repeat(1, U))
+    assoc = MultSliceAssociation(ues, U, 1, S, np.random.default_rng(0), str(tmp_path), generator_mode=False)
+    z = (np.zeros((1, U)), np.zeros((1, S)), np.zeros((S, U)), {})
+    for episode in (0, 1, 202):                      # 202 % 200 = 2
+        for step in range(3):
+            bua, bsa, sua, req = assoc.step(*z, step, episode)
+            want = objs[episode % 200]
+            assert np.array_equal(sua, want[2]) and np.array_equal(bsa, want[1]) and req == want[3]
+        s0 = int(want[4][0])
+        members = np.nonzero(want[2][s0])[0]
+        assert np.all(ues.pkt_sizes[members] == want[3][f"slice_{s0}"]["ues"]["message_size"])
+    with pytest.raises(ValueError, match="not a scenario file"):
+        np.savez(str(tmp_path / "bad.npz"), x=np.zeros(3))
+        load_episode_npz(str(tmp_path / "bad.npz"))
