@@ -77,6 +77,24 @@ SLICE_TEMPLATES: Tuple[tuple, ...] = (
      10 * _KB, 100, 8192 * 8, 0, 30, 2, 5),
 )
 SLICE_TYPE_NAMES = tuple(t[0] for t in SLICE_TEMPLATES)
+# SchedColORAN's slice-name -> use-case table (agents/sched_colran.py:356-367) as a bitmask:
+# bit 0 = eMBB (throughput rewarded), bit 1 = URLLC (buffered Mbit penalised)
+USECASE_EMBB, USECASE_URLLC = 1, 2
+SLICE_USECASE = {
+    "control_case_2": 2, "monitoring_case_1": 1, "robotic_surgery_case_1": 3, "robotic_diagnosis": 2,
+    "medical_monitoring": 1, "uav_app_case_1": 1, "uav_control_non_vlos": 1, "vr_gaming": 3,
+    "cloud_gaming": 1, "video_streaming_4k": 1,
+}
+
+
+def slice_usecase_from_req(slice_req: dict, n_slices: int) -> np.ndarray:
+    """[S] int32 use-case bits of a reference ``slice_req`` dict (0 for empty or unknown slices)."""
+    out = np.zeros(n_slices, dtype=np.int32)
+    for s in range(n_slices):
+        req = (slice_req or {}).get(f"slice_{s}", {})
+        if req:
+            out[s] = SLICE_USECASE.get(req.get("name", ""), 0)
+    return out
 MAX_AGE_CAP_DEFAULT = max(t[4] for t in SLICE_TEMPLATES)  # 400 TTIs (uav_app_case_1)
 
 

@@ -205,6 +205,20 @@ class OracleEnv:
         lib().orc_env_get_obs(self._h, _p(oi), _p(mi), _p(oa), _p(ma), _p(rw))
         return {"obs_inter": oi, "mask_inter": mi, "obs_intra": oa, "mask_intra": ma, "reward": rw}
 
+    def set_pkt_throughputs(self, thr):
+        a = np.ascontiguousarray(thr, dtype=np.float64)
+        assert a.size == self.U
+        lib().orc_env_set_pkt_throughputs(self._h, _p(a))
+
+    def heads(self, usecase):
+        """SchedTWC / SchedColORAN: (observation [10*S], reward_twc, reward_colran)."""
+        uc = np.ascontiguousarray(usecase, dtype=np.int32)
+        assert uc.size == self.S
+        obs = np.zeros(10 * self.S)
+        r1, r2 = C.c_double(0.0), C.c_double(0.0)
+        lib().orc_env_get_heads(self._h, _p(uc), _p(obs), C.byref(r1), C.byref(r2))
+        return obs, r1.value, r2.value
+
     def drift(self):
         d = np.zeros((self.S, self.Us, 3))
         lib().orc_env_get_drift(self._h, _p(d))

@@ -297,8 +297,19 @@ static void fill_se_mean(const orc_env *e, const float *se_tile, double *se_mean
 /* agents/common.py intent drift                                                   */
 /* ------------------------------------------------------------------------------ */
 
+/* The deque as an agent sees it.  IBSched pushes every raw observation once (ib_sched.py:64).
+ * SchedTWC / SchedColORAN push it twice (sched_twc.py:174-177: fake_agent.obs_space_format appends,
+ * then the head appends again), so their 10-deep deque holds the last 5 TTIs, each twice:
+ * entry i is TTI i/2.  dup = 1 or 2. */
+static int view_len(const orc_env *e, int dup)
+{
+    int n = dup * e->hist_len;
+    return n < e->cfg.hist_depth ? n : e->cfg.hist_depth;
+}
+static const raw_rec *view_at(const orc_env *e, int dup, int i) { return deque_at(e, i / dup); }
+
 /* agents/common.py:9-65 get_metric_value for one UE of slice s. */
-static double get_metric_value(const orc_env *e, int metric, int s, int ue)
+static double get_metric_value(const orc_env *e, int dup, int metric, int s, int ue)
 {
     const orc_scenario *sc = e->sc;
     const raw_rec *r0 = deque_at(e, 0);
@@ -306,9 +317,9 @@ static double get_metric_value(const orc_env *e, int metric, int s, int ue)
         return (r0->sent[ue] * (double)sc->slice_message_size[s]) / 1e6;
     if (metric == ORC_METRIC_RELIABILITY) {                            /* :32-53, pkt-loss form */
         double sent_w = 0.0, drop_w = 0.0;                             /* calc_metric_interval */
-        for (int i = 0; i < e->hist_len; i++) {
-            sent_w += deque_at(e, i)->sent[ue];
-            drop_w += deque_at(e, i)->dropped[ue];
+        for (int i = 0; i < view_len(e, dup); i++) {
+            sent_w += view_at(e, dup, i)->sent[ue];
+            drop_w += view_at(e, dup, i)->dropped[ue];
         }
         double buffer_pkts = r0->occ[ue] * (double)sc->slice_buffer_size[s] + drop_w + sent_w;
         return buffer_pkts != 0.0 ? drop_w / buffer_pkts : 0.0;
@@ -316,13 +327,13 @@ static double get_metric_value(const orc_env *e, int metric, int s, int ue)
     return r0->lat[ue];                                                /* :58-61 */
 }
 
-/* agents/common.py:68-340 intent_drift_calc (reliability_pkt_loss=True). */
-static void intent_drift_calc(orc_env *e)
+/* agents/common.py:68-340 intent_drift_calc (reliability_pkt_loss=True) into drift[S*Us*3]. */
+static void intent_drift_into(const orc_env *e, int dup, double *drift)
 {
     const orc_scenario *sc = e->sc;
     int S = e->cfg.n_slices, Us = e->cfg.max_ues_slice;
     double o = e->cfg.overfulfill;
-    memset(e->drift, 0, sizeof(double) * (size_t)S * Us * 3);
+    memset(drift, 0, sizeof(double) * (size_t)S * Us * 3);
     const raw_rec *r0 = deque_at(e, 0);
     for (int s = 0; s < S; s++) {
         if (!sc->slice_has_req[s]) continue;                           /* :86-87 */
@@ -333,12 +344,12 @@ static void intent_drift_calc(orc_env *e)
             double value = sc->param_value[s * 3 + p];
             for (int k = 0; k < n; k++) {
                 int ue = sc->slice_ues[s * Us + k];
-                double x = get_metric_value(e, metric, s, ue);
-                double *dst = &e->drift[((size_t)s * Us + k) * 3 + metric];
+                double x = get_metric_value(e, dup, metric, s, ue);
+                double *dst = &drift[((size_t)s * Us + k) * 3 + metric];
                 if (metric == ORC_METRIC_THROUGHPUT) {
-                    /* :100-119 empty buffer now or in the previous TTI => over-fulfilled */
+                    /* :100-119 empty buffer now or in the previous deque entry => over-fulfilled */
                     int zero = np_isclose(r0->occ[ue], 0.0);
-                    if (e->hist_len > 1) zero = zero || np_isclose(deque_at(e, 1)->occ[ue], 0.0);
+                    if (view_len(e, dup) > 1) zero = zero || np_isclose(view_at(e, dup, 1)->occ[ue], 0.0);
                     if (zero) x = value * (1.1 + o);
                     if (apply_op(op, x, value)) {                      /* :132-134 */
                         if (x > value * (1.0 + o)) *dst += 1.0;        /* :141-168 */
@@ -367,6 +378,8 @@ static void intent_drift_calc(orc_env *e)
         }
     }
 }
+
+static void intent_drift_calc(orc_env *e) { intent_drift_into(e, 1, e->drift); }
 
 /* ------------------------------------------------------------------------------ */
 /* agents/ib_sched.py obs_space_format + calculate_reward                          */
@@ -727,6 +740,117 @@ void orc_policy_mapf(const orc_env *e, double *inter_scores)
     }
     double ws = orc_np_sum(w, S, 1);                                   /* :105-109 */
     for (int s = 0; s < S; s++) inter_scores[s] = (ws > 0.0 ? w[s] / ws : 2.0) - 1.0;
+}
+
+/* ------------------------------------------------------------------------------ */
+/* alternative heads: SchedTWC / SchedColORAN (agents/sched_twc.py, sched_colran.py) */
+/* ------------------------------------------------------------------------------ */
+
+void orc_env_set_pkt_throughputs(orc_env *e, const double *pkt_throughputs)
+{
+    memcpy(e->pkt_throughputs, pkt_throughputs, sizeof(double) * e->cfg.n_ues);
+}
+
+/* Observation of SchedTWC.obs_space_format (sched_twc.py:165-346; SchedColORAN's is the same): slices
+ * in index order (enable_sort_slices=False, :80), metric-major:
+ *   [requirements (reliability, latency, throughput) x S | mean SE | served Mbps | effective Mbps |
+ *    buffer occupancy | buffer latency | packet loss rate | requested Mbps] = 10*S values.
+ * Rewards: SchedTWC.calculate_reward (:348-413) and SchedColORAN.calculate_reward
+ * (sched_colran.py:348-419).  usecase[s]: bit 0 = eMBB, bit 1 = URLLC (the slice-name table at
+ * sched_colran.py:356-367).  The head's deque holds every TTI twice (see view_len). */
+void orc_env_get_heads(const orc_env *e, const int32_t *usecase, double *obs, double *reward_twc,
+                       double *reward_colran)
+{
+    const orc_scenario *sc = e->sc;
+    int S = e->cfg.n_slices, Us = e->cfg.max_ues_slice;
+    const raw_rec *r0 = deque_at(e, 0);
+    double *tmp = e->scratch;
+    double *drift = (double *)malloc(sizeof(double) * (size_t)S * Us * 3);
+    intent_drift_into(e, 2, drift);
+    double *req = obs, *se = obs + 3 * S, *thr = se + S, *eff = thr + S, *occ = eff + S, *lat = occ + S,
+           *loss = lat + S, *rqt = loss + S;
+    for (int s = 0; s < S; s++) {
+        int n = sc->slice_nues[s];
+        req[3 * s] = req[3 * s + 1] = req[3 * s + 2] = 0.0;
+        if (n != 0 && sc->slice_has_req[s]) {                           /* :216-226 */
+            for (int p = 0; p < sc->slice_nparams[s]; p++) {
+                int m = sc->param_metric[s * 3 + p];
+                double v = sc->param_value[s * 3 + p];
+                if (m == ORC_METRIC_RELIABILITY) req[3 * s] = v;
+                else if (m == ORC_METRIC_LATENCY) req[3 * s + 1] = v;
+                else req[3 * s + 2] = v;
+            }
+        }
+        double pkt_size = n != 0 ? (double)sc->slice_message_size[s] : 0.0;   /* :231-237 */
+        if (n == 0) {                       /* np.mean(np.array([0])) everywhere */
+            se[s] = thr[s] = eff[s] = occ[s] = lat[s] = loss[s] = 0.0;
+        } else {
+            for (int k = 0; k < n; k++) tmp[k] = r0->se_mean[sc->slice_ues[s * Us + k]];
+            se[s] = np_mean(tmp, n, 1);                                          /* :240-252 */
+            for (int k = 0; k < n; k++) tmp[k] = e->pkt_throughputs[sc->slice_ues[s * Us + k]] * pkt_size / 1e6;
+            thr[s] = np_mean(tmp, n, 1);                                         /* :255-266 */
+            for (int k = 0; k < n; k++) tmp[k] = r0->sent[sc->slice_ues[s * Us + k]] * pkt_size / 1e6;
+            eff[s] = np_mean(tmp, n, 1);                                         /* :269-280 */
+            for (int k = 0; k < n; k++) tmp[k] = r0->occ[sc->slice_ues[s * Us + k]];
+            occ[s] = np_mean(tmp, n, 1);                                         /* :283-293 */
+            for (int k = 0; k < n; k++) tmp[k] = r0->lat[sc->slice_ues[s * Us + k]];
+            lat[s] = np_mean(tmp, n, 1);                                         /* :296-306 */
+            for (int k = 0; k < n; k++) tmp[k] = get_metric_value(e, 2, ORC_METRIC_RELIABILITY, s, sc->slice_ues[s * Us + k]);
+            loss[s] = np_mean(tmp, n, 1);                                        /* :309-322 */
+        }
+        rqt[s] = np_isclose((double)sc->slice_active[s], 1.0) ? sc->slice_traffic[s] : 0.0;   /* :325-337 */
+    }
+    /* SchedTWC.calculate_reward: negative slice drifts, weighted 2 for priority slices */
+    {
+        double vals[48], wts[48], terms[48];
+        int m = 0;
+        for (int s = 0; s < S; s++) {
+            int n = sc->slice_nues[s];
+            if (n == 0) continue;                                                /* :364-365 */
+            double sv[3] = {-2.0, -2.0, -2.0};                                   /* calculate_slice_ue_obs */
+            if (sc->slice_has_req[s])
+                for (int p = 0; p < sc->slice_nparams[s]; p++) {
+                    int mt = sc->param_metric[s * 3 + p];
+                    sv[mt] = np_mean(&drift[((size_t)s * Us) * 3 + mt], n, 3);
+                }
+            double w = sc->slice_priority[s] != 0.0 ? 2.0 : 1.0;                 /* :382-391 */
+            for (int k = 0; k < 3; k++) {
+                if (np_isclose(sv[k], -2.0)) continue;                           /* :376-378 */
+                vals[m] = sv[k] > 0.0 ? 0.0 : sv[k];                             /* :395-397 */
+                wts[m] = w; m++;
+            }
+        }
+        int q = 0; double nw[48];
+        for (int i = 0; i < m; i++) if (vals[i] < 0.0) { terms[q] = vals[i]; nw[q] = wts[i]; q++; }
+        double wsum = orc_np_sum(nw, q, 1);
+        if (np_isclose(wsum, 0.0)) *reward_twc = 0.0;                            /* :401-410 */
+        else {
+            for (int i = 0; i < q; i++) terms[i] = terms[i] * nw[i] / wsum;
+            *reward_twc = orc_np_sum(terms, q, 1);
+        }
+    }
+    /* SchedColORAN.calculate_reward: throughput of eMBB slices up, buffered Mbit of URLLC slices down */
+    {
+        double r = 0.0;
+        for (int s = 0; s < S; s++) {
+            if (sc->slice_active[s] == 0) continue;                              /* active_slice_idx */
+            int n = sc->slice_nues[s];
+            if (n == 0) continue;
+            double pkt_size = (double)sc->slice_message_size[s];
+            if (usecase[s] & 1) {
+                for (int k = 0; k < n; k++) tmp[k] = e->pkt_throughputs[sc->slice_ues[s * Us + k]];
+                double st = (np_mean(tmp, n, 1) * pkt_size) / 1e6;
+                r += st / 200.0;
+            }
+            if (usecase[s] & 2) {
+                for (int k = 0; k < n; k++) tmp[k] = r0->occ[sc->slice_ues[s * Us + k]];
+                double sb = (np_mean(tmp, n, 1) * (double)sc->slice_buffer_size[s]) * pkt_size / 1e6;
+                r -= sb / 2000.0;
+            }
+        }
+        *reward_colran = r;
+    }
+    free(drift);
 }
 
 /* ------------------------------------------------------------------------------ */

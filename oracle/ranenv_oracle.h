@@ -133,6 +133,13 @@ void orc_agent_observe(orc_env *e, const double *pkt_effective_thr, const double
                        const double *buffer_occupancies, const double *buffer_latencies,
                        const float *se_tile, const double *sched_rowsum);
 
+/* Alternative heads (SchedTWC / SchedColORAN): 10*S observation values and the two rewards computed
+ * from the same history, with the heads' double-push deque (agents/sched_twc.py:165-413,
+ * agents/sched_colran.py:348-419).  usecase[S]: bit 0 eMBB, bit 1 URLLC. */
+void orc_env_set_pkt_throughputs(orc_env *e, const double *pkt_throughputs /* U */);
+void orc_env_get_heads(const orc_env *e, const int32_t *usecase, double *obs /* 10*S */,
+                       double *reward_twc, double *reward_colran);
+
 /* Baseline policies: MARR.step (marr.py:40-47), MAPF.step (mapf.py:41-111). */
 void orc_policy_marr(const orc_env *e, double *inter_scores /* S */);
 void orc_policy_mapf(const orc_env *e, double *inter_scores /* S */);

@@ -20,6 +20,7 @@ def tables_from(fx, prefix: str = "tab_") -> ScenarioTables:
 
 AGENT_CASES = ["agent_ref_mixed", "agent_ref_rr", "agent_ref_pf_nosort", "agent_ref_mt",
                "agent_scaled_mixed", "agent_scaled_pf_nosort"]
+HEAD_CASES = ["heads_ref", "heads_scaled"]
 TRACE_CASES = ["trace_ref_random", "trace_ref_marr", "trace_ref_mapf", "trace_scaled_mapf",
                "trace_scaled_random", "trace_plumbing"]
 

@@ -7,7 +7,8 @@ travels):
     python tests/golden/gen_golden.py
 
 What is imported from the reference: agents/common.py, agents/ib_sched.py,
-agents/marr.py, agents/mapf.py, associations/mult_slice.py, traffics/mult_slice.py.
+agents/marr.py, agents/mapf.py, agents/sched_twc.py, agents/sched_colran.py (with stand-ins for the
+stable-baselines3 names their trainers import), associations/mult_slice.py, traffics/mult_slice.py.
 Their base classes come from ``sixg_radio_mgmt``, an un-vendored git submodule that is
 empty in the snapshot, so this script installs attribute-holding stand-ins for those
 base classes (constructors that store their arguments, nothing else) and a dummy
@@ -487,6 +488,120 @@ def gen_trace(name, S, U, R, G, Us, tables, scen_ids, steps_per_ep, policy, sort
     print(name, "episodes", len(scen_ids), "x", steps_per_ep)
 
 
+# ----------------------------------------------------------------------------------
+# 5. alternative heads: SchedTWC / SchedColORAN on synthetic raw observations
+# ----------------------------------------------------------------------------------
+def install_sb3_standins():
+    """agents/sched_twc.py and sched_colran.py import stable-baselines3 (absent here) for their trainers
+    only; the observation / reward code needs none of it.  Attribute-holding stand-ins, like the ones
+    for sixg_radio_mgmt above."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            pass
+
+    sys.modules["gymnasium"].Env = object
+    sys.modules["gymnasium.spaces"].Space = object
+    mod("stable_baselines3"); mod("stable_baselines3.common")
+    mod("stable_baselines3.common.callbacks", CheckpointCallback=_Stub, BaseCallback=_Stub, EvalCallback=_Stub,
+        EventCallback=_Stub)
+    mod("stable_baselines3.common.evaluation", evaluate_policy=None)
+    mod("stable_baselines3.common.vec_env", DummyVecEnv=_Stub, VecEnv=_Stub, sync_envs_normalization=None)
+    mod("stable_baselines3.ppo"); mod("stable_baselines3.ppo.ppo", PPO=_Stub)
+    mod("stable_baselines3.sac"); mod("stable_baselines3.sac.sac", SAC=_Stub)
+
+
+def infer_slice_names(tables, idx):
+    """The tables do not keep the template name; recover it from the template's own numbers."""
+    from intent_radio_sched_multi_slice_amd.scenario import SLICE_TEMPLATES
+    names = {}
+    for s in range(tables.n_slices):
+        if not tables.slice_has_req[idx, s]:
+            continue
+        key = (int(tables.slice_buffer_size[idx, s]), int(tables.slice_buffer_latency[idx, s]),
+               int(tables.slice_message_size[idx, s]), float(tables.slice_traffic[idx, s]),
+               float(tables.slice_priority[idx, s]), int(tables.slice_nparams[idx, s]))
+        hits = [t[0] for t in SLICE_TEMPLATES if (t[3], t[4], t[5], float(t[7]), float(t[1]), len(t[2])) == key]
+        assert len(hits) == 1, (key, hits)
+        names[s] = hits[0]
+    return names
+
+
+def gen_head_sequence(name, S, U, R, G, Us, tables, scen_ids, steps, seed, bw=100e6):
+    from intent_radio_sched_multi_slice_amd.scenario import slice_usecase_from_req
+    install_sb3_standins()
+    from agents.sched_twc import SchedTWC
+    from agents.sched_colran import SchedColORAN
+    from agents import sched_twc as ref_twc, sched_colran as ref_col
+    set_stable(True)
+    rng = np.random.default_rng(seed)
+    env = make_env_stub(U, R, bw, tables, scen_ids[0])
+    env.comm_env.max_number_steps = 1000
+    env.comm_env.max_number_slices = S
+    heads = []
+    for cls in (SchedTWC, SchedColORAN):
+        h = cls(env, U, S, 1, np.array([R]), checkpoint_episode_freq=1)
+        h.fake_agent.rbs_per_rbg = G
+        h.fake_agent.max_number_ues_slice = Us
+        heads.append(h)
+    rec = {k: [] for k in ("scen", "occ", "lat", "sent", "dropped", "pkt_thr", "rowsum", "head_obs", "reward_twc",
+                           "reward_colran", "usecase")}
+    sched = np.zeros((1, U, R))
+    per = steps // len(scen_ids)
+    for t in range(steps):
+        idx = scen_ids[min(t // per, len(scen_ids) - 1)]
+        env.comm_env.ues = sixg.UEs(U, tables.ue_max_age[idx].copy(), tables.ue_max_pkts[idx].copy(),
+                                    tables.ue_pkt_size[idx].copy())
+        se32 = se_tile(seed, t, U, R, low_se_every=7)
+        occ = np.zeros(U); lat = np.zeros(U); sent = np.zeros(U); dropped = np.zeros(U); thr = np.zeros(U)
+        regime = (t // 4) % 4           # 0 mixed, 1 all buffers empty, 2 nothing sent, 3 heavy loss
+        for u in range(U):
+            sl = tables.ue_slice[idx, u]
+            if sl < 0:
+                continue
+            bmax = int(tables.ue_max_pkts[idx, u]); amax = int(tables.ue_max_age[idx, u])
+            msg = int(tables.ue_pkt_size[idx, u])
+            if regime != 1 and rng.random() > 0.3:
+                occ[u] = rng.integers(1, bmax, endpoint=True) / bmax
+                lat[u] = rng.uniform(0, amax)
+            req_pkts = max(1, int(tables.slice_traffic[idx, sl] * 1e6 / msg))
+            if regime != 2 and rng.random() > 0.2:
+                sent[u] = rng.integers(0, 3 * req_pkts)
+            thr[u] = sent[u] + rng.integers(0, 2 * req_pkts)          # capacity >= packets sent
+            if (regime == 3 and rng.random() > 0.3) or rng.random() > 0.8:
+                dropped[u] = rng.integers(1, 1 + req_pkts)
+        raw = raw_dict(tables, idx, se32, occ, lat, sent, dropped, sched)
+        raw["pkt_throughputs"] = thr.copy()
+        for sl, nm in infer_slice_names(tables, idx).items():
+            raw["slice_req"][f"slice_{sl}"]["name"] = nm
+        usecase = slice_usecase_from_req(raw["slice_req"], S)
+        obs_t = np.asarray(heads[0].obs_space_format(copy.deepcopy(raw)), dtype=float)
+        obs_c = np.asarray(heads[1].obs_space_format(copy.deepcopy(raw)), dtype=float)
+        assert np.array_equal(obs_t, obs_c)
+        r_t = float(heads[0].calculate_reward(obs_t))
+        r_c = float(heads[1].calculate_reward(obs_c))
+        sc, ic = random_action(rng, S, "rand")
+        sched = np.asarray(heads[0].action_format(np.array(sc, dtype=float)))     # fixed_intra = "rr"
+        for k, v in (("scen", idx), ("occ", occ), ("lat", lat), ("sent", sent), ("dropped", dropped), ("pkt_thr", thr),
+                     ("rowsum", raw["sched_decision"][0].sum(axis=1)), ("head_obs", obs_t), ("reward_twc", r_t),
+                     ("reward_colran", r_c), ("usecase", usecase)):
+            rec[k].append(np.array(v))
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update({"tab_" + k: v for k, v in tables.arrays().items()})
+    out["cfg"] = np.array([S, U, R, G, Us, seed, 0, steps])
+    out["bw"] = np.array(bw)
+    out["stable_argsort"] = np.array(1)
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    set_stable(False)
+    print(name, "steps", steps)
+
+
 def ref_tables(n, seed, S=5, U=25, Us=5, sort=True):
     """Scenarios from the reference's own generator (associations/mult_slice.py:359-423)."""
     rng = np.random.default_rng(seed)
@@ -543,7 +658,18 @@ def main():
     gen_trace("trace_scaled_random", 10, 100, 135, 1, 10, big, [2, 3], 26, "random", True, seed=205)
     gen_trace("trace_plumbing", 2, 4, 25, 1, 4, plumbing_tables(), [0], 60, "random", True, seed=206, bw=25.0,
               max_age_cap=16, plumbing=True)
+    gen_heads()
+
+
+def gen_heads():
+    ref5_nosort = ref_tables(6, seed=10, sort=False)
+    big_nosort = generate_scaled_scenarios(4, seed=10, enable_sort_slices=False)
+    gen_head_sequence("heads_ref", 5, 25, 135, 5, 5, ref5_nosort, [0, 1, 2], 36, seed=301)
+    gen_head_sequence("heads_scaled", 10, 100, 135, 1, 10, big_nosort, [0, 3], 24, seed=302)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "heads":
+        gen_heads()          # only the SchedTWC / SchedColORAN fixtures
+    else:
+        main()

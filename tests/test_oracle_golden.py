@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
-from tests.common import AGENT_CASES, ATOL, RTOL, TRACE_CASES, load_golden, tables_from
+from tests.common import HEAD_CASES, AGENT_CASES, ATOL, RTOL, TRACE_CASES, load_golden, tables_from
 from tests.synth import se_tile
 
 
@@ -87,6 +87,29 @@ def test_agent_side_golden(case):
         assert dense.sum() == count.sum()
         if fx["mask_inter"][t].any():
             assert count.sum() == (R // G) * G            # ib_sched.py:345-347
+
+
+@pytest.mark.parametrize("case", HEAD_CASES)
+def test_alternative_heads_golden(case):
+    """SchedTWC / SchedColORAN observation (10*S values) and rewards against the reference's own classes
+    (agents/sched_twc.py:165-413, agents/sched_colran.py:348-419) on synthetic raw observations; their
+    deque holds every TTI twice, which the oracle restates."""
+    fx = load_golden(case)
+    env, (S, U, R, G, Us) = _make_env(fx)
+    tabs = tables_from(fx)
+    seed = int(fx["cfg"][5])
+    neg = 0
+    for t in range(len(fx["scen"])):
+        env.set_scenario(tabs, int(fx["scen"][t]))
+        se = se_tile(seed, t, U, R, low_se_every=7)
+        env.agent_observe(fx["sent"][t], fx["dropped"][t], fx["occ"][t], fx["lat"][t], se, fx["rowsum"][t])
+        env.set_pkt_throughputs(fx["pkt_thr"][t])
+        obs, r_twc, r_col = env.heads(fx["usecase"][t])
+        np.testing.assert_allclose(obs, fx["head_obs"][t], rtol=RTOL, atol=ATOL, err_msg=f"t={t}")
+        np.testing.assert_allclose(r_twc, fx["reward_twc"][t], rtol=RTOL, atol=ATOL, err_msg=f"twc t={t}")
+        np.testing.assert_allclose(r_col, fx["reward_colran"][t], rtol=RTOL, atol=ATOL, err_msg=f"colran t={t}")
+        neg += fx["reward_twc"][t] < 0
+    assert neg > 3 and np.abs(fx["reward_colran"]).max() > 0     # the fixtures exercise both rewards
 
 
 @pytest.mark.parametrize("case", TRACE_CASES)
