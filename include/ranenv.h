@@ -207,6 +207,22 @@ int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);
 
+/* Alternative heads.  SchedTWC and SchedColORAN (agents/sched_twc.py, agents/sched_colran.py)
+ * are single-agent wrappers around IBSched: same action_format with fixed_intra = "rr" (sched_twc.py:415-422,
+ * i.e. ranenv_set_policy(EXTERNAL, RR) + ranenv_step with inter-slice scores), but their own observation
+ * (sched_twc.py:165-346: per slice 3 requirement values and 7 slice means, slices in index order, laid out
+ * metric-major: [reliability, latency, throughput req of slice 0, ... of slice S-1 | mean SE x S | served Mbps |
+ * effective Mbps | buffer occupancy | buffer latency | packet-loss rate | requested Mbps]) and rewards
+ * (sched_twc.py:348-413; sched_colran.py:348-419).  Once outputs are bound, reset / step / step_dense also
+ * launch the head kernel:
+ *   dev_obs_head    float32 [B][10*S]
+ *   dev_reward_head float64 [B][2]     [0] SchedTWC.calculate_reward, [1] SchedColORAN.calculate_reward
+ * NULL, NULL unbinds.  The heads read pkt_throughputs, so they refuse RANENV_F_NO_RAW_OUTPUT. */
+int ranenv_bind_head_outputs(ranenv_handle h, float *dev_obs_head, double *dev_reward_head);
+/* SchedColORAN's slice-name table (sched_colran.py:356-367) as data: host array [count][S], bit 0 = eMBB,
+ * bit 1 = URLLC, for scenario-pool rows [first, first+count).  Default 0 (no reward term). */
+int ranenv_set_slice_usecase(ranenv_handle h, int32_t first, int32_t count, const int32_t *usecase, void *stream);
+
 /* Channel ingest: QuaDRiGa received power -> spectral efficiency, element by element,
  *     se = float32( log2(1 + tx_power_per_rb * g / (0 + noise_power)) )            (float64 arithmetic)
  * replaces QuadrigaChannel.step's per-TTI transform (channels/quadriga.py:56-69; tx_power_per_rb =

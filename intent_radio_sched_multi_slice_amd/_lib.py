@@ -21,7 +21,7 @@ EXPORTS = (
     "ranenv_load_scenarios", "ranenv_bind_se_pool", "ranenv_bind_traffic_pool", "ranenv_set_episodes",
     "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_step_profiled",
     "ranenv_get_views",
-    "ranenv_launch_info", "ranenv_se_from_power",
+    "ranenv_launch_info", "ranenv_se_from_power", "ranenv_bind_head_outputs", "ranenv_set_slice_usecase",
 )
 
 
@@ -107,6 +107,8 @@ def load() -> C.CDLL:
     lib.ranenv_get_views.argtypes = [C.c_void_p, C.POINTER(Views)]
     lib.ranenv_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ranenv_se_from_power.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]
+    lib.ranenv_bind_head_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ranenv_set_slice_usecase.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     if lib.ranenv_abi_version() != ABI_VERSION:
         raise RanEnvError(f"ABI mismatch: library {lib.ranenv_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

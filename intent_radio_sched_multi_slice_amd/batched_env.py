@@ -221,6 +221,30 @@ class BatchedRanEnv:
         return self._obs(), self.reward, self.done
 
     # ------------------------------------------------------------------------------------------
+    def enable_heads(self, slice_usecase=None):
+        """Also compute the SchedTWC / SchedColORAN observation and rewards every TTI
+        (agents/sched_twc.py:165-413, agents/sched_colran.py:348-419).
+
+        ``self.head_obs``  float32 [B, 10*S]: per slice 3 requirement values, then the slice means of SE,
+        served Mbps, effective Mbps, buffer occupancy, buffer latency, loss rate and the requested Mbps
+        (metric-major, slices in index order); ``self.head_reward`` float64 [B, 2] = (SchedTWC, SchedColORAN).
+        ``slice_usecase``: int [n_scenarios, S], bit 0 eMBB / bit 1 URLLC (scenario.slice_usecase_from_req).
+        Their action is IBSched's with round-robin inside the slices: ``set_policy(POLICY_EXTERNAL, INTRA_RR)``.
+        """
+        self.head_obs = torch.zeros((self.B, 10 * self.S), dtype=torch.float32, device=self.device)
+        self.head_reward = torch.zeros((self.B, 2), dtype=torch.float64, device=self.device)
+        self._check(self._lib.ranenv_bind_head_outputs(self._h, _ptr(self.head_obs), _ptr(self.head_reward)),
+                    "ranenv_bind_head_outputs")
+        if slice_usecase is not None:
+            self.set_slice_usecase(slice_usecase)
+
+    def set_slice_usecase(self, slice_usecase, first: int = 0):
+        uc = np.ascontiguousarray(slice_usecase, dtype=np.int32).reshape(-1, self.S)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_slice_usecase(self._h, int(first), uc.shape[0], C.c_void_p(uc.ctypes.data),
+                                                           self._stream()), "ranenv_set_slice_usecase")
+
+    # ------------------------------------------------------------------------------------------
     def views(self) -> Dict[str, torch.Tensor]:
         """Zero-copy torch views of the handle's raw-observation and state arrays."""
         if self._views is None:

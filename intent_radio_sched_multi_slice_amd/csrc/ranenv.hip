@@ -61,6 +61,7 @@ struct Tables {  // scenario pool on the device, rows of [n_scenarios]
     double  *param_f64;  // [NS][S][3]
     int32_t *slice_ues;  // [NS][S][Us]
     int32_t *slot_ue, *slot_mp, *slot_pk;   // [NS][S*16] UE id (-1 = empty slot), its max_pkts / pkt_size
+    int32_t *slice_usecase;                 // [NS][S] SchedColORAN: bit 0 eMBB, bit 1 URLLC
     int32_t *ue_slice, *ue_pos, *ue_pkt_size, *ue_max_pkts, *ue_max_age;  // [NS][U]
 };
 
@@ -88,6 +89,8 @@ struct KP {
     const uint8_t *dense;
     // outputs (may be null)
     float *obs_inter; float *obs_intra; double *reward; uint8_t *done;
+    // alternative heads (SchedTWC / SchedColORAN), bound by ranenv_bind_head_outputs
+    float *head_obs; double *head_reward;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -869,6 +872,197 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 #endif
 }
 
+// =============================================================================================
+// Alternative heads: the observation of SchedTWC / SchedColORAN (agents/sched_twc.py:165-346:
+// 3 requirements + 7 slice means per slice, slices in index order, metric-major) and their rewards
+// (sched_twc.py:348-413, sched_colran.py:348-419), from the state the core kernel just wrote.
+// One workgroup = one env, thread = slot (slice, UE position), launched after the core kernel when
+// head outputs are bound.
+//
+// These agents push every raw observation twice into their 10-deep deque (sched_twc.py:174-177), so
+// their window is the last D/2 TTIs counted twice, and "the previous entry" is the current TTI again:
+// entry i of their deque is TTI i/2 of the window ring.
+// =============================================================================================
+struct SharedHead {
+    double rows[GRP][10][GRP];    // per slice: mean SE, served Mbps, effective Mbps, occupancy, latency, loss,
+                                  //            raw capacity, drift x3 -- by UE position, zero padded
+    double sv[GRP][3];            // slice drift means (-2: not declared)
+    double thr_raw[GRP], occ_m[GRP];
+    int nues[GRP];
+};
+
+// numpy pairwise_sum of n < 128 doubles by one lane
+DEVFN double np_sum_seq(const double *a, int n)
+{
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+__global__ void __launch_bounds__(ALLOC_NT) ranenv_head_kernel(const KP p)
+{
+    __shared__ SharedHead sh;
+    auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
+    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;
+    const int S = p.S, U = p.U, D = p.D;
+    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
+    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);      // counters after this TTI's push
+    const int npush = __builtin_amdgcn_readfirstlane(p.st.n_push[e]);
+    const int s = tid / GRP, pos = tid % GRP;
+    const bool in_grid = s < S;
+    const int NS16 = S * GRP;
+    int ue = -1, mp = 1;
+    if (tid < NS16) { const size_t ts = (size_t)sc * NS16 + tid; ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; }
+    const bool have = ue >= 0;
+    const int gsh = (tid & 63) & ~(GRP - 1);
+    const int n = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));
+    int active = 0, has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0, usecase = 0;
+    int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
+    double pv[3] = {0.0, 0.0, 0.0}, priority = 0.0, traffic_tab = 0.0;
+    if (in_grid) {
+        const size_t row = (size_t)sc * S + s;
+        const int32_t *si = p.tab.slice_i32 + row * 8;
+        active = si[0]; has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
+        usecase = p.tab.slice_usecase[row];
+        priority = p.tab.slice_f64[row * 2 + 0]; traffic_tab = p.tab.slice_f64[row * 2 + 1];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pm[k] = p.tab.param_i32[(row * 3 + k) * 2 + 0];
+            po[k] = p.tab.param_i32[(row * 3 + k) * 2 + 1];
+            pv[k] = p.tab.param_f64[row * 3 + k];
+        }
+    }
+    // ---- the UE of this slot ----------------------------------------------------------------------
+    double vals[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (have) {
+        const size_t su = (size_t)e * U + ue;
+        const int total = p.st.queue_pkts[su];
+        const long long sum_age = p.st.queue_age_sum[su];
+        const double sem = p.st.se_mean[su];
+        const double sent = (double)p.st.pkt_effective_thr[su], thr = (double)p.st.pkt_throughputs[su];
+        // the heads' window: deque entry i is TTI i/2; view_len = min(2*hlen, D)
+        const int vlen = 2 * hlen < D ? 2 * hlen : D;
+        double sw = 0.0, dw = 0.0;
+        for (int j = 0; 2 * j < vlen; j++) {
+            int idx = npush - 1 - j; idx += idx < 0 ? D : 0;
+            const double mult = 2 * j + 1 < vlen ? 2.0 : 1.0;
+            sw += mult * (double)p.st.ring_sent[((size_t)e * D + idx) * U + ue];
+            dw += mult * (double)p.st.ring_drop[((size_t)e * D + idx) * U + ue];
+        }
+        const double occ = (double)total / (double)mp;
+        const double lat = total > 0 ? (double)sum_age / (double)total : 0.0;
+        const double bp = occ * (double)bsize + dw + sw;                     // common.py:32-53
+        const double loss = bp != 0.0 ? dw / bp : 0.0;
+        vals[0] = sem;
+        vals[1] = thr * (double)msg / 1e6;                                   // sched_twc.py:255-266
+        vals[2] = sent * (double)msg / 1e6;                                  // :269-280
+        vals[3] = occ; vals[4] = lat; vals[5] = loss; vals[6] = thr;
+        if (has_req) {                                                       // common.py:68-340, heads' deque
+            const double o = p.over;
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) {
+                if (qi < npar) {
+                    const int metric = pm[qi], op = po[qi];
+                    const double value = pv[qi];
+                    double res;
+                    if (metric == RANENV_METRIC_THROUGHPUT) {
+                        double x = (sent * (double)msg) / 1e6;
+                        if (d_isclose(occ, 0.0)) x = value * (1.1 + o);      // entry 1 of their deque = this TTI
+                        if (d_apply_op(op, x, value)) res = (x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o);
+                        else res = -((value - x) / value);
+                    } else if (metric == RANENV_METRIC_RELIABILITY) {
+                        const double x = loss;
+                        const double band = (100.0 - value) / 100.0;
+                        if (d_apply_op(op, 100.0 * (1.0 - x), value)) res = (x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o);
+                        else res = -((x - band) / (value / 100.0));
+                    } else {
+                        const double x = lat;
+                        if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
+                        else res = -((x - value) / ((double)blat - value));
+                    }
+                    vals[7] = metric == 0 ? res : vals[7]; vals[8] = metric == 1 ? res : vals[8]; vals[9] = metric == 2 ? res : vals[9];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; k++) sh.rows[s][k][pos] = vals[k];
+    wave_sync();
+    // ---- the slice (lane 0 of its 16 writes) -------------------------------------------------------
+    if (in_grid && pos == 0) {
+        float *o = p.head_obs ? p.head_obs + (size_t)e * 10 * S : nullptr;
+        double m[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (n > 0) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) m[k] = np_sum16_lds(sh.rows[s][k], n) / (double)n;
+        }
+        double sv[3] = {-2.0, -2.0, -2.0};
+        double req[3] = {0.0, 0.0, 0.0};
+        if (n > 0 && has_req) {
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) {
+                if (qi < npar) {
+                    const int mt = pm[qi];
+                    const double mean = np_sum16_lds(sh.rows[s][7 + mt], n) / (double)n;
+                    sv[0] = mt == 0 ? mean : sv[0]; sv[1] = mt == 1 ? mean : sv[1]; sv[2] = mt == 2 ? mean : sv[2];
+                    // requirements = [reliability, latency, throughput]            sched_twc.py:216-226
+                    req[0] = mt == RANENV_METRIC_RELIABILITY ? pv[qi] : req[0];
+                    req[1] = mt == RANENV_METRIC_LATENCY ? pv[qi] : req[1];
+                    req[2] = mt == RANENV_METRIC_THROUGHPUT ? pv[qi] : req[2];
+                }
+            }
+        }
+        if (o) {
+            o[3 * s + 0] = (float)req[0]; o[3 * s + 1] = (float)req[1]; o[3 * s + 2] = (float)req[2];
+#pragma unroll
+            for (int k = 0; k < 6; k++) o[(3 + k) * S + s] = (float)m[k];
+            o[9 * S + s] = (float)(d_isclose((double)active, 1.0) ? traffic_tab : 0.0);  // :325-337
+        }
+        sh.sv[s][0] = sv[0]; sh.sv[s][1] = sv[1]; sh.sv[s][2] = sv[2];
+        sh.thr_raw[s] = m[6]; sh.occ_m[s] = m[3];
+        sh.nues[s] = n;
+    }
+    __syncthreads();
+    // ---- the rewards (one lane; a few dozen values) ------------------------------------------------
+    if (tid == 0 && p.head_reward) {
+        double terms[3 * GRP], nw[3 * GRP];
+        int q = 0;
+        double r_col = 0.0;
+        for (int sl = 0; sl < S; sl++) {
+            const int nu = sh.nues[sl];
+            if (nu == 0) continue;                                               // sched_twc.py:364-365
+            const size_t row = (size_t)sc * S + sl;
+            const double w = p.tab.slice_f64[row * 2 + 0] != 0.0 ? 2.0 : 1.0;    // :382-391
+            for (int k = 0; k < 3; k++) {
+                const double v = sh.sv[sl][k];
+                if (d_isclose(v, -2.0) || !(v < 0.0)) continue;                  // :376-378, :395-399
+                terms[q] = v; nw[q] = w; q++;
+            }
+            const int32_t *si = p.tab.slice_i32 + row * 8;
+            if (si[0] != 0) {                                                    // sched_colran.py:372-419
+                const int uc = p.tab.slice_usecase[row];
+                const double pkt = (double)si[5];
+                if (uc & 1) r_col += ((sh.thr_raw[sl] * pkt) / 1e6) / 200.0;
+                if (uc & 2) r_col -= ((sh.occ_m[sl] * (double)si[3]) * pkt / 1e6) / 2000.0;
+            }
+        }
+        const double wsum = np_sum_seq(nw, q);
+        double r_twc = 0.0;
+        if (!d_isclose(wsum, 0.0)) {
+            for (int i = 0; i < q; i++) terms[i] = terms[i] * nw[i] / wsum;
+            r_twc = np_sum_seq(terms, q);
+        }
+        p.head_reward[(size_t)e * 2 + 0] = r_twc;
+        p.head_reward[(size_t)e * 2 + 1] = r_col;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Channel ingest: received power -> spectral efficiency (channels/quadriga.py:56-69), elementwise.
 // 8 B read + 4 B written per element; two elements per thread and grid-stride, 16-byte loads.
@@ -959,6 +1153,7 @@ hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream)
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[2], stream);
+    if (kp.head_obs || kp.head_reward) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
     return hipGetLastError();
 }
 
@@ -1017,6 +1212,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     {
         const size_t NSL = (size_t)S * GRP;
         ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
+        ALLOC(kp.tab.slice_usecase, NS * S);
     }
     ALLOC(h->d_episodes, B);
 #undef ALLOC
@@ -1266,6 +1462,28 @@ int ranenv_get_views(ranenv_handle h, ranenv_views *out)
     out->win_sent = (int64_t *)s.win_sent; out->win_dropped = (int64_t *)s.win_dropped;
     out->step_number = s.step_no; out->hist_len = s.hist_len;
     out->mask_inter = s.mask_inter; out->mask_intra = s.mask_intra; out->policy_scores = s.policy_scores;
+    return RANENV_OK;
+}
+
+int ranenv_bind_head_outputs(ranenv_handle h, float *dev_obs_head, double *dev_reward_head)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if ((dev_obs_head || dev_reward_head) && (h->cfg.flags & RANENV_F_NO_RAW_OUTPUT))
+        return fail(h, RANENV_E_STATE, "the heads read pkt_throughputs: not available with RANENV_F_NO_RAW_OUTPUT");
+    h->kp.head_obs = dev_obs_head; h->kp.head_reward = dev_reward_head;
+    return RANENV_OK;
+}
+
+int ranenv_set_slice_usecase(ranenv_handle h, int32_t first, int32_t count, const int32_t *usecase, void *stream_)
+{
+    if (!h || !usecase) return fail(h, RANENV_E_INVALID, "null argument");
+    if (first < 0 || count < 1 || first + count > h->cfg.n_scenarios) return fail(h, RANENV_E_INVALID, "scenario rows [%d,%d) outside pool of %d", first, first + count, h->cfg.n_scenarios);
+    const size_t n = (size_t)count * h->cfg.n_slices;
+    for (size_t i = 0; i < n; i++) if (usecase[i] < 0 || usecase[i] > 3) return fail(h, RANENV_E_INVALID, "use-case bits must be in [0,3]");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(h, hipMemcpyAsync(h->kp.tab.slice_usecase + (size_t)first * h->cfg.n_slices, usecase, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
     return RANENV_OK;
 }
 

@@ -173,3 +173,59 @@ def test_se_from_power_matches_the_reference_formula():
         assert ulp.max() <= 1, ulp.max()
         assert (ulp != 0).mean() <= 1e-3
         assert got[0, 0, 0] == 0.0
+
+
+def test_alternative_heads_vs_oracle():
+    """SchedTWC / SchedColORAN observation and rewards from the head kernel against the oracle (itself pinned
+    to the reference's classes by tests/golden/heads_*.npz), in closed loop: external scores, round-robin
+    inside the slices as their action_format does, a masked reset in the middle."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.scenario import SLICE_TEMPLATES, SLICE_USECASE
+    steps = 16
+    env, tabs, scen, se_pool, trf, dims = _setup(steps=steps, B=6, seed=9)
+    S, U, R, G, Us = dims
+    # use-case bits per scenario row, recovered from the template numbers
+    uc = np.zeros((tabs.n_scenarios, S), dtype=np.int32)
+    for i in range(tabs.n_scenarios):
+        for s in range(S):
+            if tabs.slice_has_req[i, s]:
+                key = (int(tabs.slice_buffer_size[i, s]), int(tabs.slice_buffer_latency[i, s]),
+                       int(tabs.slice_message_size[i, s]), float(tabs.slice_traffic[i, s]))
+                name = [t[0] for t in SLICE_TEMPLATES if (t[3], t[4], t[5], float(t[7])) == key][0]
+                uc[i, s] = SLICE_USECASE[name]
+    env.enable_heads(uc)
+    env.set_policy(0, 0)                       # scores from the caller, round-robin intra-slice
+    oenvs = _oracles(tabs, scen, dims, steps)
+    env.reset()
+    for b, o in enumerate(oenvs):
+        o.reset(se_pool[b * steps])
+    rng = np.random.default_rng(4)
+    t0 = np.zeros(len(oenvs), dtype=np.int64)
+    saw_neg = saw_col = False
+
+    def check(tag):
+        nonlocal saw_neg, saw_col
+        ho, hr = env.head_obs.cpu().numpy(), env.head_reward.cpu().numpy()
+        for b, o in enumerate(oenvs):
+            obs, r_twc, r_col = o.heads(uc[scen[b]])
+            np.testing.assert_allclose(ho[b], obs, rtol=1e-6, atol=OBS_TOL, err_msg=f"{tag} env {b}")
+            np.testing.assert_allclose(hr[b], [r_twc, r_col], rtol=0, atol=REW_TOL, err_msg=f"{tag} env {b}")
+            saw_neg |= r_twc < 0; saw_col |= r_col != 0
+
+    check("reset")
+    for t in range(12):
+        if t == 7:
+            mask = (np.arange(len(oenvs)) % 2 == 0).astype(np.uint8)
+            env.reset(env_mask=mask)
+            for b in np.nonzero(mask)[0]:
+                t0[b] = t
+                oenvs[b].reset(se_pool[b * steps])
+            check("masked reset")
+        sc = rng.uniform(-1, 1, (len(oenvs), S)); ic = np.zeros((len(oenvs), S), dtype=np.uint8)
+        env.step(sc, ic)
+        for b, o in enumerate(oenvs):
+            k = b * steps + int(t - t0[b])
+            o.step(sc[b], ic[b], se_pool[k], trf[k])
+        check(f"t={t}")
+    assert saw_neg and saw_col
+    env.close()
