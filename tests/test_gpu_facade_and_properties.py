@@ -155,3 +155,60 @@ def test_full_batch_properties():
         env.close()
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
     assert torch.equal(finals[0][2], finals[1][2])
+
+
+def test_full_episode_vs_oracle():
+    """A whole 1000-TTI episode at the headline sizes (buffer_latency up to 400 TTIs, so the per-UE age
+    list wraps and long-lived packets expire), MAPF + PF on the device, against the oracle: integer state
+    every 50 TTIs, observation and reward at the end, done exactly at max_steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    from oracle import pyoracle
+    from tests.common import poisson_traffic_rows
+    from tests.synth import se_tile
+    S, U, R, G, Us, B, steps, L = 10, 100, 135, 1, 10, 4, 1000, 40
+    tabs = generate_scaled_scenarios(3, seed=21)
+    rng = np.random.default_rng(22)
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    se_pool = np.stack([se_tile(77, t, U, R, low_se_every=5) for t in range(B * L)])      # traces of 40 tiles, replayed
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, L) for b in range(B)])
+    trf[::3] *= 3.0                                                                       # overload: queues fill, packets age out
+    env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+                        n_scenarios=tabs.n_scenarios, max_steps=steps)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se_pool, -1, -2)), device=env.device))
+    env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=scen, se_base=np.arange(B) * L, se_len=L, trf_base=np.arange(B) * L, trf_len=L)
+    env.set_policy(2, 1)
+    cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+    oenvs = []
+    for b in range(B):
+        o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * L]); oenvs.append(o)
+    env.reset()
+    ic = np.ones(S, dtype=np.int32)
+    expired = 0
+    for t in range(steps):
+        obs, rew, done = env.step()
+        for b, o in enumerate(oenvs):
+            k = b * L + t % L
+            o.step(o.policy_mapf(), ic, se_pool[k], trf[k])
+        assert bool(done.all()) == (t + 1 == steps)
+        if (t + 1) % 50 == 0 or t + 1 == steps:
+            g = {k: x.cpu().numpy() for k, x in env.views().items()}
+            gro = {k: x.cpu().numpy() for k, x in env.raw_observation().items()}
+            for b, o in enumerate(oenvs):
+                raw = o.raw()
+                for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                    assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (t, b, name)
+                assert np.array_equal(gro["buffer_occupancies"][b], raw["buffer_occupancies"]), (t, b)
+                assert np.array_equal(gro["buffer_latencies"][b], raw["buffer_latencies"]), (t, b)
+                expired += int(raw["buffer_latencies"].max() > 100)
+    for b, o in enumerate(oenvs):
+        oo = o.obs()
+        np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(obs["obs_intra"][b].cpu().numpy(), oo["obs_intra"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=1e-9)
+    assert expired > 0, "the episode never held packets for more than 100 TTIs: the test lost its point"
+    env.close()
