@@ -43,8 +43,8 @@
 #define DEVFN __device__ __forceinline__
 
 #ifndef RANENV_DIAG
-#define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the core kernel, 6-7 of the alloc kernel,
-                           9 stamps s_memtime per phase (tools/stamps.py, tools/kprobe.py) */
+#define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the core kernel, 6 leaves only the launch of
+                           the alloc kernel, 9 stamps s_memtime per phase (tools/stamps.py, tools/kprobe.py) */
 #endif
 
 namespace {
@@ -282,7 +282,8 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     full = lf + rf; part = lg + rg;
 }
 
-#if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of wave 0 / wave 1 at phase boundaries */
+#if RANENV_DIAG == 9   /* diagnostic build: s_memtime of wave 0 / wave 1 at phase boundaries (the counter ticks at
+                          about the shader clock on this part; only ratios are used) */
 #define RANENV_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (k) + 5 * (int)(threadIdx.x >> 6) < p.S) \
     p.st.policy_scores[(size_t)(p.e0 + blockIdx.x) * p.S + (k) + 5 * (threadIdx.x >> 6)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
 #else
