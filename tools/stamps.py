@@ -1,5 +1,5 @@
 """Diagnostic: s_memtime phase stamps of the step kernel (build with -DRANENV_DIAG=9, run with
-RANENV_LIB=tools/diag9.so RANENV_FUSE=0).  Slots 0-4: wave 0 at entry / stream start / stream end /
+RANENV_LIB=tools/diag9.so).  Slots 0-4: wave 0 at entry / stream start / stream end /
 UE step end / after the barrier; slots 5-8: the same for wave 1; slot 9: end of the obs tail."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
