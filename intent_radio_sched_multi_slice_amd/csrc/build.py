@@ -31,6 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUT
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+           "-ffp-contract=off",     # numpy rounds a*b and +c separately; fma() is written out where it is exact
            "-I", os.path.join(REPO, "include"), SRC, "-o", OUT + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -235,9 +235,11 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     auto consume = [&](const float (&x)[8], int r0) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float xs = in(r0 + j) ? x[j] : 0.0f;
-            f[j] += (double)x[j];
-            g[j] += (double)xs;
+            // part += sched * se with sched in {0, 1}: one fused multiply-add is exact here (the product is
+            // either x or 0), and cheaper than selecting a 64-bit addend
+            const double d = (double)x[j];
+            f[j] += d;
+            g[j] = fma(d, in(r0 + j) ? 1.0 : 0.0, g[j]);
         }
         if (--left_in_leaf == 0) {
             fr = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
@@ -255,9 +257,9 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             if (j < tail) {
-                const float xs = in(r0 + j) ? x[j] : 0.0f;
-                fr += (double)x[j];
-                gr += (double)xs;
+                const double d = (double)x[j];
+                fr += d;
+                gr = fma(d, in(r0 + j) ? 1.0 : 0.0, gr);
             }
         }
         fold(pl.n_leaves - 1);
@@ -707,36 +709,46 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
+        // The slice lists up to three parameters in its own order; the lanes of a wave belong to different
+        // slices, so "for each parameter: switch on its metric" would run all three formulas three times.
+        // Instead: find this slice's (value, operator) for each metric, then run each formula once.
         double dres[3] = {0.0, 0.0, 0.0};
         if (slc >= 0 && has_req) {
             const double o = p.over;
-    #pragma unroll
-            for (int qi = 0; qi < 3; qi++) {
-                if (qi < npar) {
-                    const int metric = pm[qi], op = po[qi];
-                    const double value = pv[qi];
-                    double res;
-                    if (metric == RANENV_METRIC_THROUGHPUT) {
-                        double x = ((double)sent * (double)msg) / 1e6;                  // common.py:25-31
-                        bool zero = d_isclose(occ_new, 0.0);                            // :100-119
-                        if (hlen_new > 1) zero = zero || d_isclose(occ_prev, 0.0);
-                        if (zero) x = value * (1.1 + o);
-                        if (d_apply_op(op, x, value)) res = (x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o);
-                        else res = -((value - x) / value);
-                    } else if (metric == RANENV_METRIC_RELIABILITY) {
-                        const double dw = (double)win_drop, sw = (double)win_sent;      // :32-53
-                        const double buffer_pkts = occ_new * (double)bsize + dw + sw;
-                        const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
-                        const double band = (100.0 - value) / 100.0;
-                        if (d_apply_op(op, 100.0 * (1.0 - x), value)) res = (x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o);
-                        else res = -((x - band) / (value / 100.0));
-                    } else {
-                        const double x = lat_new;                                       // :58-61
-                        if (d_apply_op(op, x, value)) res = (x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o);
-                        else res = -((x - value) / ((double)blat - value));
-                    }
-                    dres[metric] = res;
+            bool dec[3] = {false, false, false};
+            double val[3] = {1.0, 1.0, 1.0};
+            int opm[3] = {0, 0, 0};
+#pragma unroll
+            for (int qi = 0; qi < 3; qi++) {          // a later parameter for the same metric overwrites (:132-335)
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    const bool hit = qi < npar && pm[qi] == m;
+                    dec[m] = dec[m] || hit; val[m] = hit ? pv[qi] : val[m]; opm[m] = hit ? po[qi] : opm[m];
                 }
+            }
+            if (dec[RANENV_METRIC_THROUGHPUT]) {
+                const double value = val[RANENV_METRIC_THROUGHPUT];
+                double x = ((double)sent * (double)msg) / 1e6;                          // common.py:25-31
+                bool zero = d_isclose(occ_new, 0.0);                                    // :100-119
+                if (hlen_new > 1) zero = zero || d_isclose(occ_prev, 0.0);
+                if (zero) x = value * (1.1 + o);
+                dres[RANENV_METRIC_THROUGHPUT] = d_apply_op(opm[RANENV_METRIC_THROUGHPUT], x, value)
+                    ? ((x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o)) : -((value - x) / value);
+            }
+            if (dec[RANENV_METRIC_RELIABILITY]) {
+                const double value = val[RANENV_METRIC_RELIABILITY];
+                const double dw = (double)win_drop, sw = (double)win_sent;              // :32-53
+                const double buffer_pkts = occ_new * (double)bsize + dw + sw;
+                const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
+                const double band = (100.0 - value) / 100.0;
+                dres[RANENV_METRIC_RELIABILITY] = d_apply_op(opm[RANENV_METRIC_RELIABILITY], 100.0 * (1.0 - x), value)
+                    ? ((x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o)) : -((x - band) / (value / 100.0));
+            }
+            if (dec[RANENV_METRIC_LATENCY]) {
+                const double value = val[RANENV_METRIC_LATENCY];
+                const double x = lat_new;                                               // :58-61
+                dres[RANENV_METRIC_LATENCY] = d_apply_op(opm[RANENV_METRIC_LATENCY], x, value)
+                    ? ((x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o)) : -((x - value) / ((double)blat - value));
             }
         }
 
