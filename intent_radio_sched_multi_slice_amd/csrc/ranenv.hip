@@ -618,7 +618,10 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
     RANENV_STAMP(2);
-    const double occ_prev = (double)total / (double)max_pkts;
+    // np.isclose(previous buffer occupancy, 0) (common.py:108-118): occupancy = total / max_pkts.  Exact
+    // shortcuts: an empty queue is 0; a queue above 2e-8 * max_pkts is not close to 0; in between, divide.
+    bool prev_empty = total == 0;
+    if (total != 0 && !((double)total > 2e-8 * (double)max_pkts)) prev_empty = d_isclose((double)total / (double)max_pkts, 0.0);
 #if RANENV_DIAG == 3 || RANENV_DIAG == 5
     if (act && my_full < -1.0) {
 #else
@@ -726,14 +729,17 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
                     dec[m] = dec[m] || hit; val[m] = hit ? pv[qi] : val[m]; opm[m] = hit ? po[qi] : opm[m];
                 }
             }
+            // Each formula is "intent met ? a / b : -(c / d)" (plus a cap at 1 when over-fulfilled): one division
+            // on the selected operands gives the bits of whichever arm is taken.
             if (dec[RANENV_METRIC_THROUGHPUT]) {
                 const double value = val[RANENV_METRIC_THROUGHPUT];
                 double x = ((double)sent * (double)msg) / 1e6;                          // common.py:25-31
                 bool zero = d_isclose(occ_new, 0.0);                                    // :100-119
-                if (hlen_new > 1) zero = zero || d_isclose(occ_prev, 0.0);
+                if (hlen_new > 1) zero = zero || prev_empty;
                 if (zero) x = value * (1.1 + o);
-                dres[RANENV_METRIC_THROUGHPUT] = d_apply_op(opm[RANENV_METRIC_THROUGHPUT], x, value)
-                    ? ((x > value * (1.0 + o)) ? 1.0 : (x - value) / (value * o)) : -((value - x) / value);
+                const bool met = d_apply_op(opm[RANENV_METRIC_THROUGHPUT], x, value);
+                const double q = (met ? x - value : value - x) / (met ? value * o : value);
+                dres[RANENV_METRIC_THROUGHPUT] = met ? ((x > value * (1.0 + o)) ? 1.0 : q) : -q;
             }
             if (dec[RANENV_METRIC_RELIABILITY]) {
                 const double value = val[RANENV_METRIC_RELIABILITY];
@@ -741,14 +747,16 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
                 const double buffer_pkts = occ_new * (double)bsize + dw + sw;
                 const double x = buffer_pkts != 0.0 ? dw / buffer_pkts : 0.0;
                 const double band = (100.0 - value) / 100.0;
-                dres[RANENV_METRIC_RELIABILITY] = d_apply_op(opm[RANENV_METRIC_RELIABILITY], 100.0 * (1.0 - x), value)
-                    ? ((x < band * (1.0 - o)) ? 1.0 : (band - x) / (band * o)) : -((x - band) / (value / 100.0));
+                const bool met = d_apply_op(opm[RANENV_METRIC_RELIABILITY], 100.0 * (1.0 - x), value);
+                const double q = (met ? band - x : x - band) / (met ? band * o : value / 100.0);
+                dres[RANENV_METRIC_RELIABILITY] = met ? ((x < band * (1.0 - o)) ? 1.0 : q) : -q;
             }
             if (dec[RANENV_METRIC_LATENCY]) {
                 const double value = val[RANENV_METRIC_LATENCY];
                 const double x = lat_new;                                               // :58-61
-                dres[RANENV_METRIC_LATENCY] = d_apply_op(opm[RANENV_METRIC_LATENCY], x, value)
-                    ? ((x < value * (1.0 - o)) ? 1.0 : (value - x) / (value * o)) : -((x - value) / ((double)blat - value));
+                const bool met = d_apply_op(opm[RANENV_METRIC_LATENCY], x, value);
+                const double q = (met ? value - x : x - value) / (met ? value * o : (double)blat - value);
+                dres[RANENV_METRIC_LATENCY] = met ? ((x < value * (1.0 - o)) ? 1.0 : q) : -q;
             }
         }
 
