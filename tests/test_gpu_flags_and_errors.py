@@ -229,3 +229,36 @@ def test_alternative_heads_vs_oracle():
         check(f"t={t}")
     assert saw_neg and saw_col
     env.close()
+
+
+def test_trainer_adapters():
+    """HeadVecEnv follows the VecEnv protocol (shapes, dtypes, auto-reset with terminal_observation) and hands
+    out the head kernel's numbers; the MARL dicts are the batched tensors of one env under the reference's keys."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.adapters import HeadVecEnv, marl_obs_dict, marl_reward_dict
+    steps = 5
+    env, tabs, scen, se_pool, trf, dims = _setup(steps=steps, B=4, seed=13)
+    S, U, R, G, Us = dims
+    venv = HeadVecEnv(env, reward="colran", slice_usecase=np.full((tabs.n_scenarios, S), 3, dtype=np.int32))
+    obs = venv.reset()
+    assert obs.shape == (4, 10 * S) and obs.dtype == np.float32 and venv.num_envs == 4
+    assert venv.action_space.shape == (S,) and venv.observation_space.shape == (10 * S,)
+    rng = np.random.default_rng(0)
+    for t in range(2 * steps):
+        obs, rew, dones, infos = venv.step(rng.uniform(-1, 1, (4, S)))
+        assert obs.shape == (4, 10 * S) and rew.shape == (4,) and rew.dtype == np.float32 and dones.dtype == bool
+        end = (t + 1) % steps == 0
+        assert bool(dones.all()) == end and bool(dones.any()) == end
+        if end:
+            assert all("terminal_observation" in i for i in infos)
+            assert int(env.views()["step_number"].max()) == 0          # auto-reset happened
+            np.testing.assert_array_equal(obs, env.head_obs.cpu().numpy())
+        else:
+            np.testing.assert_allclose(rew, env.head_reward[:, 1].cpu().numpy().astype(np.float32))
+    d = marl_obs_dict(env, 2); r = marl_reward_dict(env, 2)
+    assert set(d) == {f"player_{i}" for i in range(S + 1)} == set(r)
+    assert d["player_0"]["observations"].shape == (10 * S,) and d["player_0"]["action_mask"].shape == (S,)
+    assert d["player_3"]["observations"].shape == (2 * Us + 9,) and d["player_3"]["action_mask"].shape == (Us,)
+    with pytest.raises(ValueError):
+        venv.step(np.zeros((3, S)))
+    venv.close()
