@@ -188,7 +188,7 @@ class MimicQuadriga(Channel):
 
 class PoolChannel(Channel):
     """Replay of a precomputed SE array [episodes][steps][U][R] (what channels/quadriga.py:38-76 does
-    from target_cell_power.mat after log2(1 + P*g/N); the HDF5 reader itself is out of scope)."""
+    from target_cell_power.mat after log2(1 + P*g/N); QuadrigaChannel below reads the files themselves)."""
 
     def __init__(self, *a, pool: Optional[np.ndarray] = None, **k):
         super().__init__(*a, **k)
@@ -197,6 +197,64 @@ class PoolChannel(Channel):
     def step(self, step_number, episode_number, mobilities, sched_decision=None):
         ep = self.pool[episode_number % self.pool.shape[0]]
         return ep[step_number % ep.shape[0]][None, :, :]
+
+
+class QuadrigaChannel(Channel):
+    """channels/quadriga.py:9-87: replay of QuaDRiGa channel files.
+
+    ``{root_path}/mult_slice_channel_generation/results/mult_slice/freq_channel/assoc_{A}/ep_{E}/
+    target_cell_power.mat`` is opened when the episode changes (:45-54); per TTI the step-th slice of
+    ``target_cell_power`` goes through ``log2(1 + (P/R)*g / (0 + noise))`` and is transposed to
+    ``(1, U, R)`` (:56-76).  (A, E) = (episode, 0) (:78-87).  The files are MATLAB v7.3 = HDF5: ``h5py`` is
+    imported when the first file is opened and its absence is an error here, not a silent fallback.
+    """
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.scenario_name = "mult_slice"          # the reference always uses this folder (:27-29)
+        self.current_episode_number = -1
+        self.file = None
+        self.channels_path = f"{self.root_path}/mult_slice_channel_generation/results/{self.scenario_name}/freq_channel/"
+        self.spectral_efficiencies = np.array([])
+        self.transmission_power = 100              # Watts
+        self.thermal_noise_power = 10e-14
+        self.channel_eps_per_scenario = 100
+
+    def _open(self, path: str):
+        try:
+            import h5py
+        except ImportError as exc:
+            raise ImportError("QuadrigaChannel reads MATLAB v7.3 (HDF5) files and needs h5py") from exc
+        return h5py.File(path, "r")
+
+    def choose_episode(self, episode_number: int, current_episode: int):
+        if episode_number != current_episode:
+            return episode_number, 0, True
+        return 0, 0, False
+
+    def step(self, step_number, episode_number, mobilities, sched_decision=None):
+        assoc, ep, changed = self.choose_episode(episode_number, self.current_episode_number)
+        if changed:
+            self.current_episode_number = episode_number
+            if self.file is not None:
+                self.file.close()
+            self.file = self._open(f"{self.channels_path}assoc_{assoc}/ep_{ep}/target_cell_power.mat")
+        if self.file is None:
+            raise ValueError("File is None")
+        power = np.array(self.file.get("target_cell_power")[step_number, :, :, :, :])
+        se = quadriga_se_from_power(power, int(self.num_available_rbs[0]), self.transmission_power,
+                                    self.thermal_noise_power)
+        self.spectral_efficiencies = np.squeeze(se.transpose())
+        return np.array([self.spectral_efficiencies])
+
+
+class QuadrigaChannelSeq(QuadrigaChannel):
+    """channels/quadriga_seq.py:28-39: (A, E) = (episode // 100, episode % 100)."""
+
+    def choose_episode(self, episode_number: int, current_episode: int):
+        if episode_number != current_episode:
+            return episode_number // self.channel_eps_per_scenario, episode_number % self.channel_eps_per_scenario, True
+        return 0, 0, False
 
 
 def quadriga_se_from_power(target_cell_power: np.ndarray, n_rbs: int, transmission_power: float = 100.0,

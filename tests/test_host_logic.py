@@ -208,3 +208,47 @@ def test_scenario_file_roundtrip_and_replay(tmp_path):
     with pytest.raises(ValueError, match="not a scenario file"):
         np.savez(str(tmp_path / "bad.npz"), x=np.zeros(3))
         load_episode_npz(str(tmp_path / "bad.npz"))
+
+
+def test_quadriga_channel_plugin_with_a_fake_hdf5_file(tmp_path, monkeypatch):
+    """channels/quadriga.py:38-87 and quadriga_seq.py:28-39: which file is opened for which episode, the
+    per-step slice, the log2(1 + SNR) transform and the (1, U, R) orientation.  h5py is absent here, so the
+    file object is a stand-in with the two calls the plugin makes (File(path, "r").get(name)[...])."""
+    from intent_radio_sched_multi_slice_amd import plugins
+    U, R, T = 6, 9, 4
+    rng = np.random.default_rng(3)
+    store, opened = {}, []
+
+    class FakeFile:
+        def __init__(self, path):
+            self.path = path
+            opened.append(path)
+            store.setdefault(path, 10.0 ** rng.uniform(-14, -9, size=(T, R, 1, 1, U)))   # [step][R][1][1][U]
+
+        def get(self, name):
+            assert name == "target_cell_power"
+            return store[self.path]
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(plugins.QuadrigaChannel, "_open", lambda self, path: FakeFile(path))
+    ch = plugins.QuadrigaChannel(U, 1, np.array([R]), np.random.default_rng(0), str(tmp_path), "whatever")
+    for episode, step in ((0, 0), (0, 3), (2, 1)):
+        se = ch.step(step, episode, None)
+        path = f"{tmp_path}/mult_slice_channel_generation/results/mult_slice/freq_channel/assoc_{episode}/ep_0/target_cell_power.mat"
+        assert opened[-1] == path and se.shape == (1, U, R)
+        g = store[path][step, :, 0, 0, :]                                   # (R, U)
+        want = np.log2(1 + (100 / R) * g / (0 + 10e-14)).T
+        np.testing.assert_array_equal(se[0], want)
+    assert len(opened) == 2                                                 # one open per episode change
+    seq = plugins.QuadrigaChannelSeq(U, 1, np.array([R]), np.random.default_rng(0), str(tmp_path), "x")
+    seq.step(0, 205, None)
+    assert opened[-1].endswith("assoc_2/ep_5/target_cell_power.mat")
+    # without h5py the real opener fails loudly
+    monkeypatch.undo()
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="needs h5py"):
+            plugins.QuadrigaChannel(U, 1, np.array([R]), None, str(tmp_path), "x").step(0, 0, None)
