@@ -179,9 +179,6 @@ DEVFN RowPlan make_row_plan(int n)
     return pl;
 }
 
-#ifndef RANENV_SE_AUX
-#define RANENV_SE_AUX 0   /* cache policy bits of the SE loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1) */
-#endif
 #ifndef RANENV_SE_DEPTH
 #define RANENV_SE_DEPTH 3
 #endif
@@ -190,21 +187,23 @@ constexpr int SE_NQ = RANENV_SE_DEPTH;   // 8-row groups in flight per lane
 struct SeStream {
     float q[SE_NQ][8];
     __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
-    int voff, row_bytes, r_last;
+    int voff, row_bytes;
 
     DEVFN void load(float (&dst)[8], int r0)
     {
+        // rows past the tile (the padding of the last, partial group) fall outside the descriptor's
+        // num_records: the buffer load returns 0 for them, no clamp needed
+        int soff = r0 * row_bytes;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int r = r0 + j;
-            const int rr = r < r_last ? r : r_last;                       // scalar clamp: always in bounds
-            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, rr * row_bytes, RANENV_SE_AUX));
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+            soff += row_bytes;
         }
     }
     DEVFN void init(const float *tile, int U, int u, int R)
     {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
-        voff = u * 4; row_bytes = U * 4; r_last = R - 1;
+        voff = u * 4; row_bytes = U * 4;
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
