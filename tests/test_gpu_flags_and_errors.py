@@ -18,7 +18,7 @@ def _need_gpu():
         pytest.skip("needs an MI355X")
 
 
-def _setup(flags=0, steps=12, B=4, seed=3):
+def _setup(flags=0, steps=12, B=4, seed=3, hist_depth=10):
     from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     S, U, R, G, Us = 5, 25, 135, 1, 5
@@ -28,7 +28,7 @@ def _setup(flags=0, steps=12, B=4, seed=3):
     se_pool = np.stack([se_tile(33, t, U, R) for t in range(B * steps)])
     trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
     env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
-                        n_scenarios=tabs.n_scenarios, max_steps=steps, flags=flags)
+                        n_scenarios=tabs.n_scenarios, max_steps=steps, flags=flags, hist_depth=hist_depth)
     env.load_scenarios(tabs)
     env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se_pool, -1, -2)), device=env.device))
     env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
@@ -36,10 +36,10 @@ def _setup(flags=0, steps=12, B=4, seed=3):
     return env, tabs, scen, se_pool, trf, (S, U, R, G, Us)
 
 
-def _oracles(tabs, scen, dims, steps):
+def _oracles(tabs, scen, dims, steps, hist_depth=10):
     from oracle import pyoracle
     S, U, R, G, Us = dims
-    cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+    cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps, hist_depth=hist_depth)
     out = []
     for b in range(len(scen)):
         o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, int(scen[b])); out.append(o)
@@ -175,14 +175,16 @@ def test_se_from_power_matches_the_reference_formula():
         assert got[0, 0, 0] == 0.0
 
 
-def test_alternative_heads_vs_oracle():
+@pytest.mark.parametrize("hist_depth", [10, 5])
+def test_alternative_heads_vs_oracle(hist_depth):
     """SchedTWC / SchedColORAN observation and rewards from the head kernel against the oracle (itself pinned
     to the reference's classes by tests/golden/heads_*.npz), in closed loop: external scores, round-robin
-    inside the slices as their action_format does, a masked reset in the middle."""
+    inside the slices as their action_format does, a masked reset in the middle.  hist_depth 5: an odd deque
+    length, where the oldest TTI of the heads' doubled window counts once."""
     _need_gpu()
     from intent_radio_sched_multi_slice_amd.scenario import SLICE_TEMPLATES, SLICE_USECASE
     steps = 16
-    env, tabs, scen, se_pool, trf, dims = _setup(steps=steps, B=6, seed=9)
+    env, tabs, scen, se_pool, trf, dims = _setup(steps=steps, B=6, seed=9, hist_depth=hist_depth)
     S, U, R, G, Us = dims
     # use-case bits per scenario row, recovered from the template numbers
     uc = np.zeros((tabs.n_scenarios, S), dtype=np.int32)
@@ -195,7 +197,7 @@ def test_alternative_heads_vs_oracle():
                 uc[i, s] = SLICE_USECASE[name]
     env.enable_heads(uc)
     env.set_policy(0, 0)                       # scores from the caller, round-robin intra-slice
-    oenvs = _oracles(tabs, scen, dims, steps)
+    oenvs = _oracles(tabs, scen, dims, steps, hist_depth)
     env.reset()
     for b, o in enumerate(oenvs):
         o.reset(se_pool[b * steps])
