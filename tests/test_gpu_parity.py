@@ -198,6 +198,7 @@ def test_batch_vs_oracle(policy, intra, size):
     dict(S=16, U=128, R=300, G=3, Us=16),  # three leaves (150 -> 72+78 | 150), full slot grid
     dict(S=6, U=64, R=408, G=8, Us=11),    # four leaves, G does not divide R
     dict(S=16, U=256, R=64, G=1, Us=16),   # the largest UE count of this build: four waves per env
+    dict(S=5, U=30, R=48, G=2, Us=8, D=3),  # a 3-deep observation window: the ring wraps every three TTIs
 ])
 @pytest.mark.parametrize("variant", ["external", "device"])
 def test_shapes_vs_oracle(shape, variant):
@@ -208,6 +209,7 @@ def test_shapes_vs_oracle(shape, variant):
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     from oracle import pyoracle
     S, U, R, G, Us = (shape[k] for k in ("S", "U", "R", "G", "Us"))
+    D = shape.get("D", 10)
     tabs = generate_scaled_scenarios(3, seed=5, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=max(1, S // 2),
                                      min_ues=max(1, Us // 3))
     B, steps = 6, 14
@@ -215,14 +217,14 @@ def test_shapes_vs_oracle(shape, variant):
     scen = rng.integers(0, tabs.n_scenarios, B)
     se_pool = np.stack([se_tile(90, t, U, R) for t in range(B * steps)])
     env = _env(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
-               n_scenarios=tabs.n_scenarios, max_steps=steps)
+               n_scenarios=tabs.n_scenarios, max_steps=steps, hist_depth=D)
     env.load_scenarios(tabs)
     env.bind_se_pool(torch.as_tensor(_rb_major(se_pool), device=env.device))
     trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
     env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
     env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
     env.set_policy(0, 255) if variant == "external" else env.set_policy(2, 1)
-    ocfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+    ocfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps, hist_depth=D)
     oenvs = []
     for b in range(B):
         o = pyoracle.OracleEnv(ocfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
