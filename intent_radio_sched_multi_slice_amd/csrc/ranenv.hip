@@ -140,6 +140,20 @@ DEVFN bool d_apply_op(int op, double a, double b)
     }
 }
 
+// Sums and inclusive scans over the 16 lanes of a DPP row (= one slice's lanes): data-parallel-primitive
+// moves inside the VALU instead of ds_bpermute round trips through the LDS crossbar.
+template <int CTRL> DEVFN int dpp_row(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+DEVFN int row16_sum(int x)          // every lane gets the sum of its row: rotate right by 1, 2, 4, 8
+{
+    x += dpp_row<0x121>(x); x += dpp_row<0x122>(x); x += dpp_row<0x124>(x); x += dpp_row<0x128>(x);
+    return x;
+}
+DEVFN int row16_scan(int x)         // inclusive prefix sum: shift right by 1, 2, 4, 8 (zeros shifted in)
+{
+    x += dpp_row<0x111>(x); x += dpp_row<0x112>(x); x += dpp_row<0x114>(x); x += dpp_row<0x118>(x);
+    return x;
+}
+
 constexpr int WAVE = 64;
 constexpr int GRP = 16;   // lanes per (env) group in alloc1/obs and per (env, slice) group in alloc2
 
@@ -396,9 +410,7 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
         if (tid < GRP) {
             const double tot = np_sum16_lds(xs[2], m_nz);
             const int my_prop = nzf ? (int)((double)T * my_v / tot) : 0;                  // :488-490 (value >= 0)
-            int acc = my_prop;
-#pragma unroll
-            for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+            const int acc = row16_sum(my_prop);
             const int adj = T - acc;                                                     // :493-499
             int extra = 0;
             if (nzf && adj > 0) {
@@ -408,9 +420,7 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
                 extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
             }
             const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
-            int incl = mine;
-#pragma unroll
-            for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (s1 >= d) ? v : 0; }
+            const int incl = row16_scan(mine);
             sa.rbs[s1] = mine; sa.off[s1] = incl - mine;
         }
     }
@@ -458,9 +468,7 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
     if (use_round) {
         const double tot = np_sum16_lds(ra, m_v);
         const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
-        int acc = prop;
-#pragma unroll
-        for (int d = 1; d < GRP; d <<= 1) acc += __shfl_xor(acc, d, GRP);
+        const int acc = row16_sum(prop);
         const int adj = n_rbs - acc;
         count = prop;
         if (nzv && adj > 0) {
@@ -481,9 +489,7 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
     }
-    int incl = count;                                                              // :464-478 contiguous ranges
-#pragma unroll
-    for (int d = 1; d < GRP; d <<= 1) { const int v = __shfl_up(incl, d, GRP); incl += (pos >= d) ? v : 0; }
+    const int incl = row16_scan(count);                                            // :464-478 contiguous ranges
     if (have) {
         p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
         p.st.rb_count[(size_t)e * U + ue] = count;
