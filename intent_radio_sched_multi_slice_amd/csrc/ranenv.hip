@@ -400,12 +400,12 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
             nzf = my_v != 0.0;
             // compaction of the non-zero values in slice order (common.py:484-485)
-            const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull);
-            m_nz = __popc(gm); slot = __popc(gm & ((1u << s1) - 1u));
-            xs[2][s1] = 0.0;
+            // non-zero values move to the front in slice order, the zeros fill the slots behind them: every
+            // slot is written exactly once, so the row needs no clearing pass
+            const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull), below = (1u << s1) - 1u;
+            m_nz = __popc(gm); slot = nzf ? __popc(gm & below) : m_nz + __popc(~gm & below);
+            xs[2][slot] = my_v; xs[3][s1] = my_v;
         }
-        wave_sync();
-        if (tid < GRP) { if (nzf) xs[2][slot] = my_v; xs[3][s1] = my_v; }
         wave_sync();
         if (tid < GRP) {
             const double tot = np_sum16_lds(xs[2], m_nz);
@@ -457,11 +457,10 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
     const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
     const bool nzv = my_val != 0.0;
     const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
-    const int m_v = __popc(gmv), slot_v = __popc(gmv & ((1u << pos) - 1u));
-    wave_sync();
-    ra[pos] = 0.0;
-    wave_sync();
-    if (nzv) ra[slot_v] = my_val;                                                  // compaction (:484-485)
+    const unsigned below = (1u << pos) - 1u;
+    const int m_v = __popc(gmv), slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below);
+    wave_sync();                                                                   // everyone has read rb / ra
+    ra[slot_v] = my_val;                                                           // compaction (:484-485); zeros go behind
     rb[pos] = my_val;
     wave_sync();
     int count = 0;
