@@ -496,7 +496,7 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
 }
 
 
-__global__ void __launch_bounds__(ALLOC_NT) ranenv_alloc_kernel(const KP p)
+__global__ void __launch_bounds__(ALLOC_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) ranenv_alloc_kernel(const KP p)
 {
     __shared__ SharedAlloc sa;
     const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
