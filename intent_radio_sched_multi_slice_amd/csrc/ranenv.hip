@@ -391,12 +391,12 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
         if (tid < GRP) {
             my_a = (ok1 && active) ? xs[3][sorted] : -1.0;                                           // ib_sched.py:247-255
             xs[0][s1] = ok1 ? my_a + 1.0 : 0.0;
-            xs[1][s1] = ok1 ? (double)active : 0.0;
         }
         wave_sync();
         double my_v = 0.0; bool nzf = false; int m_nz = 0, slot = 0;
         if (tid < GRP) {
-            const double ssum = np_sum16_lds(xs[0], S), asum = np_sum16_lds(xs[1], S);
+            // np.sum(association) adds small integers: exact in any order, so an integer row sum does it
+            const double ssum = np_sum16_lds(xs[0], S), asum = (double)row16_sum(ok1 ? active : 0);
             if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
             nzf = my_v != 0.0;
             // compaction of the non-zero values in slice order (common.py:484-485)
