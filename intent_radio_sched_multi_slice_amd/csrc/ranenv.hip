@@ -44,7 +44,8 @@
 
 #ifndef RANENV_DIAG
 #define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the core kernel, 6 leaves only the launch of
-                           the alloc kernel, 9 stamps s_memtime per phase (tools/stamps.py, tools/kprobe.py) */
+                           the alloc kernel, 8 / 9 stamp s_memtime per phase of the alloc / core kernel
+                           (tools/stamps_alloc.py, tools/stamps.py) */
 #endif
 
 namespace {
@@ -297,6 +298,12 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     full = lf + rf; part = lg + rg;
 }
 
+#if RANENV_DIAG == 8   /* diagnostic build: s_memtime of thread 0 of the alloc kernel at phase boundaries; dumped
+                          into policy_scores[e][0..6] at the end (tools/stamps_alloc.py) */
+#define ALLOC_STAMP(k) alloc_tt[k] = __builtin_amdgcn_s_memtime()
+#else
+#define ALLOC_STAMP(k) do { } while (0)
+#endif
 #if RANENV_DIAG == 9   /* diagnostic build: s_memtime of wave 0 / wave 1 at phase boundaries (the counter ticks at
                           about the shader clock on this part; only ratios are used) */
 #define RANENV_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (k) + 5 * (int)(threadIdx.x >> 6) < p.S) \
@@ -332,6 +339,11 @@ struct SharedAlloc {
 DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
                        int ue, int n, int q, int mp, int pk, long long wsent, double sem)
 {
+#if RANENV_DIAG == 8
+    unsigned long long alloc_tt[8];
+    alloc_tt[0] = 0;
+#endif
+    ALLOC_STAMP(1);
     auto &xs = sa.xs; auto &rows = sa.rows;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     const int tid = threadIdx.x;
@@ -353,7 +365,9 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
         const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s1) * 8;
         active = si[0]; nues1 = si[2]; bsize = si[3]; msg = si[5]; sorted = si[7];
     }
+    ALLOC_STAMP(2);
     __syncthreads();
+    ALLOC_STAMP(3);
     if (tid < WAVE) {            // wave 0; the other waves go straight to the barrier below
         double score = -1.0;
         if (mapf) {
@@ -424,7 +438,9 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             sa.rbs[s1] = mine; sa.off[s1] = incl - mine;
         }
     }
+    ALLOC_STAMP(4);
     __syncthreads();
+    ALLOC_STAMP(5);
 
     // ---- intra-slice: 16 lanes per slice ---------------------------------------------------------
     const int n_rbs = s < S ? sa.rbs[s] : 0, off = s < S ? sa.off[s] : 0;
@@ -493,6 +509,10 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
         p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
         p.st.rb_count[(size_t)e * U + ue] = count;
     }
+#if RANENV_DIAG == 8
+    ALLOC_STAMP(6);
+    if (tid == 0) for (int k = 1; k < 7 && k < S; k++) p.st.policy_scores[(size_t)e * S + k] = (double)(alloc_tt[k] - alloc_tt[1]);
+#endif
 }
 
 
