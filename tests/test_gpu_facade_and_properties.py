@@ -212,3 +212,41 @@ def test_full_episode_vs_oracle():
         np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=1e-9)
     assert expired > 0, "the episode never held packets for more than 100 TTIs: the test lost its point"
     env.close()
+
+
+def test_full_batch_long_run():
+    """B = 4096 for a whole 1000-TTI episode plus a reset: packets are conserved over the run, the age list
+    (401 entries per UE) wraps, long-queued packets expire, everything stays finite and in bounds, and the
+    episode ends exactly at max_steps."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd import _lib
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    wl = make_mult_slice_workload(4096, dev, policy=_lib.POLICY_MAPF, intra=_lib.INTRA_PF, n_traces=40, trace_len=50)
+    env = wl.env
+    env.reset()
+    v = env.views()
+    scen = torch.as_tensor(wl.scenario, device=dev)
+    max_pkts = torch.as_tensor(wl.tables.ue_max_pkts, device=dev)[scen].to(torch.int64)
+    max_age = torch.as_tensor(wl.tables.ue_max_age, device=dev)[scen].to(torch.int64)
+    net = torch.zeros_like(max_pkts)
+    dropped_total = torch.zeros((), dtype=torch.int64, device=dev)
+    for t in range(1000):
+        obs, rew, done = env.step()
+        net += v["pkt_incoming"].to(torch.int64) - v["pkt_effective_thr"].to(torch.int64) - v["dropped_pkts"].to(torch.int64)
+        dropped_total += v["dropped_pkts"].to(torch.int64).sum()
+        if (t + 1) % 100 == 0:
+            q = v["queue_pkts"].to(torch.int64)
+            assert torch.equal(q, net), t
+            assert torch.all((q >= 0) & (q <= max_pkts))
+            age = v["queue_age_sum"]
+            assert torch.all(age >= 0) and torch.all(age <= q * max_age)          # no packet older than its budget
+            assert torch.isfinite(rew).all() and torch.isfinite(obs["obs_inter"]).all() and torch.isfinite(obs["obs_intra"]).all()
+            assert bool(done.all()) == (t + 1 == 1000)
+    assert int(dropped_total) > 0 and int((v["queue_age_sum"] > 150 * v["queue_pkts"].to(torch.int64)).sum()) > 0
+    env.reset()
+    assert int(v["queue_pkts"].abs().sum()) == 0 and int(v["step_number"].max()) == 0
+    for _ in range(5):
+        obs, rew, done = env.step()
+    assert torch.isfinite(rew).all() and not bool(done.any())
+    env.close()
