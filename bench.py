@@ -5,9 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one TTI of every env of the batch = one launch of the fused HIP kernel
-(device MAPF policy -> inter-slice split -> PF intra-slice -> UEs.step -> intent observation
-and reward).  Workload at N=1: BASELINE.json configs[2], the configuration the north_star's
+One "step" = one TTI of every env of the batch (device MAPF policy -> inter-slice split -> PF
+intra-slice -> UEs.step -> intent observation and reward).  Workload at N=1: BASELINE.json configs[2], the configuration the north_star's
 throughput target is quoted on (mult_slice, 10 slices / 100 UEs / 135 RBGs, batch 4096, PF
 intra-slice + ib_sched intent reward); with N GPUs every rank steps its own 4096 envs (weak
 scaling; N=8 is configs[3], batch 32768 sharded 8x).  Inputs (scenario, SE and traffic pools)
@@ -76,16 +75,78 @@ def cpu_baseline(wl, sample_envs: int, sample_steps: int):
             "sample": f"{n} envs x {sample_steps} TTIs of the same workload, oracle/ranenv_oracle.c, OpenMP over envs, {dt:.2f} s"}
 
 
+def rank_env():
+    """(world, rank, local_rank) from the launcher's environment (torch.distributed.run)."""
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def timed_steps(step_fn, n_steps: int, sync_fn, barrier_fn, max_over_ranks_fn):
+    """EXACTLY n_steps calls of step_fn bracketed by barrier + device sync on both sides; wall-clock
+    seconds, MAX over ranks.  Shared with tests/test_bench_logic.py (gloo, stub env)."""
+    sync_fn(); barrier_fn(); sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step_fn()
+    sync_fn(); barrier_fn(); sync_fn()
+    return max_over_ranks_fn(time.perf_counter() - t0)
+
+
+def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed, kernel_ms, traffic, metrics,
+               workload_extra=""):
+    """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region;
+    the per-kernel device durations (HIP events on the launch stream, same K steps repeated with events
+    on) are listed beside them."""
+    S, U, R = env_sizes
+    total_env_steps = batch * world * args.steps
+    value = total_env_steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    alg_bytes = alg_bytes_env_step * batch                       # per launch (= one TTI of one rank's batch)
+    achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9            # per-GPU GB/s on the wall clock
+    dev_ms = sum(v for k, v in kernel_ms.items() if k != "n_steps")
+    dom = max((k for k in kernel_ms if k != "n_steps"), key=lambda k: kernel_ms[k])
+    dom_bytes = alg_bytes if kernel_ms.get("alloc", 0.0) == 0.0 else (alg_bytes_env_step - S * 5) * batch
+    dom_gbs = dom_bytes / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
+    return {
+        "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{args.config}]: {label}; batch {batch} per GPU; SE replayed from "
+                               f"an HBM pool of {args.traces}x{args.trace_len} float32 tiles{workload_extra}",
+                   "batch_per_gpu": batch, "global_batch": batch * world, "n_slices": S, "n_ues": U,
+                   "n_rbs": R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "clock": "wall clock of the timed region (same as value)",
+                     "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
+                     "traffic_source": traffic.get("source") if traffic else None,
+                     "kernel": "one TTI = " + " + ".join(k for k in kernel_ms if k != "n_steps" and kernel_ms[k] > 0),
+                     "algorithmic_bytes_per_env_step": alg_bytes_env_step,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "device_ms_per_step": dev_ms,
+                     "frac_device": (alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms > 0 else None,
+                     "kernels_ms": {k: v for k, v in kernel_ms.items() if k != "n_steps"},
+                     "kernels_ms_source": f"HIP events on the launch stream around each kernel, {kernel_ms.get('n_steps', 0)} "
+                                          "steps repeated right after the timed region",
+                     "dominant_kernel": {"name": dom, "ms": kernel_ms[dom], "algorithmic_bytes": dom_bytes,
+                                         "achieved": dom_gbs, "frac": dom_gbs / HBM_PEAK_GBS}},
+        "metrics": metrics,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--config", type=int, default=2, choices=(1, 2),
-                    help="BASELINE.json configs index: 1 = B1024 MARR+RR, 2 = B4096 MAPF+PF (default)")
+    ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's own)")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="BASELINE.json configs index: 1 = B1024 MARR+RR, 2 = B4096 MAPF+PF (default; 3 = the same "
+                         "per GPU, i.e. what --gpus 8 runs), 4 = mult_slice_seq sweep B8192, mixed masks")
     ap.add_argument("--traces", type=int, default=200)
     ap.add_argument("--trace-len", type=int, default=200)
+    ap.add_argument("--traffic", choices=("pool", "philox"), default="pool",
+                    help="offered traffic: replayed Poisson pool (parity mode) or the device counter-based generator")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,11 +156,9 @@ def main():
     import torch.distributed as dist
     from intent_radio_sched_multi_slice_amd import _lib
     from intent_radio_sched_multi_slice_amd.dist import gather_metrics, local_metrics, summarize
-    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = rank_env()
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -111,83 +170,49 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    if args.config == 1:
-        batch = 1024 if args.batch == 4096 else args.batch
-        policy, intra, label = _lib.POLICY_MARR, _lib.INTRA_RR, "MARR inter-slice + round-robin intra-slice"
-    else:
-        batch, policy, intra = args.batch, _lib.POLICY_MAPF, _lib.INTRA_PF
-        label = "MAPF inter-slice + PF intra-slice + ib_sched intent observation/reward"
-    wl = make_mult_slice_workload(batch, device, policy=policy, intra=intra, n_traces=args.traces,
-                                  trace_len=args.trace_len, rank=rank)
+    wl, label = make_bench_workload(args.config, device, batch=args.batch, n_traces=args.traces,
+                                    trace_len=args.trace_len, rank=rank, traffic=args.traffic)
     env = wl.env
+    batch = env.B
     env.reset()
     for _ in range(args.warmup):
-        obs, reward, done = env.step()
-    gather_metrics(local_metrics(reward, env.views(), done, 1))   # warm torch's reduction kernels / RCCL
-    ev_start = torch.cuda.Event(enable_timing=True)
-    ev_end = torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev_start.record()               # torch's current stream = the stream the kernels are launched on
-    for i in range(args.steps):
-        obs, reward, done = env.step()
-    ev_end.record()
-    vec = local_metrics(reward, env.views(), done, args.steps)
-    gathered = gather_metrics(vec)      # the only collective: metrics, RCCL all_gather
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    step_ms = ev_start.elapsed_time(ev_end) / args.steps      # device time of one TTI (3 kernels)
-    prof = [env.step_profiled() for _ in range(24)][4:]       # per-kernel HIP events, after the timed region
-    kms = {k: float(np.mean([q[k] for q in prof])) for k in ("alloc", "core")}
-    total_env_steps = batch * world * args.steps
-    value = total_env_steps / elapsed
+        env.step()
+    gather_metrics(local_metrics(env.reward, env.views(), env.done, 1))   # warm torch's reduction kernels / RCCL
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    barrier = dist.barrier if world > 1 else (lambda: None)
+    elapsed = timed_steps(env.step, args.steps, torch.cuda.synchronize, barrier, max_over_ranks)
+    # metrics: the only collective, once per reporting interval, outside the timed K steps
+    gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, args.steps))
+    # the same K steps again with HIP events around every kernel (on the stream they are launched on)
+    env.profile_begin(args.steps)
+    for _ in range(args.steps):
+        env.step()
+    kms = env.profile_end()
+    kernel_ms = {"alloc": kms["alloc"], "core": kms["core"], "n_steps": kms["n_steps"]}
 
     if rank == 0:
-        alg_bytes = env.algorithmic_bytes_per_env_step() * batch          # per TTI of the whole batch
-        achieved = alg_bytes / (step_ms * 1e-3) / 1e9                     # whole step: alloc + core + obs
-        # the dominant kernel (core) moves everything except the action term of SURVEY 8(d)
-        core_bytes = (env.algorithmic_bytes_per_env_step() - env.S * 5) * batch
-        core_gbs = core_bytes / (kms["core"] * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if tj.get("batch") == batch and tj.get("config") == args.config:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
+                               "source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this "
+                                         f"workload, {tj.get('date', 'undated')}; not measured in this run)"}
             except Exception:
                 traffic = None
-        line = {
-            "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{args.config}]: mult_slice, 10 slices, 100 UEs, 135 RBGs, "
-                                   f"batch {batch} per GPU, {label}; SE replayed from an HBM pool of "
-                                   f"{args.traces}x{args.trace_len} float32 tiles, Poisson traffic pool",
-                       "batch_per_gpu": batch, "global_batch": batch * world, "n_slices": env.S, "n_ues": env.U,
-                       "n_rbs": env.R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "one TTI = ranenv_alloc_kernel + ranenv_core_kernel<STEP>",
-                         "kernel_ms": step_ms,
-                         "algorithmic_bytes_per_env_step": env.algorithmic_bytes_per_env_step(),
-                         "dominant_kernel": {"name": "ranenv_core_kernel<STEP>", "ms": kms["core"],
-                                             "algorithmic_bytes": core_bytes, "achieved": core_gbs,
-                                             "frac": core_gbs / HBM_PEAK_GBS},
-                         "other_kernels_ms": {"alloc": kms["alloc"]}},
-            "metrics": summarize(gathered.cpu()),
-        }
+        line = build_line(args, world, batch, label, (env.S, env.U, env.R), env.algorithmic_bytes_per_env_step(),
+                          elapsed, kernel_ms, traffic, summarize(gathered.cpu()),
+                          workload_extra=(", Poisson traffic pool" if args.traffic == "pool"
+                                          else ", Poisson traffic drawn on the device (Philox4x32-10)"))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_envs, args.cpu_steps)
         print(json.dumps(line), flush=True)

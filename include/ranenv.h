@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 1
+#define RANENV_ABI_VERSION 2
 
 enum {
     RANENV_OK = 0,
@@ -64,6 +64,9 @@ enum { RANENV_OP_GE = 0, RANENV_OP_LE = 1, RANENV_OP_EQ = 2, RANENV_OP_GT = 3, R
 #define RANENV_F_CLEAR_HISTORY_ON_RESET 0x1 /* default off: the reference never clears the
                                                10-TTI window (agents/ib_sched.py:51)      */
 #define RANENV_F_NO_RAW_OUTPUT          0x2 /* skip pkt_incoming / pkt_throughputs stores  */
+#define RANENV_F_SYNC_CHECK             0x4 /* debug: reset / step / step_dense wait for their
+                                               kernels and return RANENV_E_HIP on an asynchronous
+                                               fault instead of leaving it to a later call     */
 
 typedef struct ranenv *ranenv_handle;
 
@@ -198,9 +201,12 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
 
-/* Diagnostic: one TTI (device policy, bound pools, no observation outputs) with HIP events
- * around each kernel; blocks until it finished.  ms2 = {alloc, core} durations in ms. */
-int ranenv_step_profiled(ranenv_handle h, float *ms2, void *stream);
+/* Per-kernel timing of ordinary steps: after ranenv_profile_begin every reset / step / step_dense call
+ * records HIP events around each of its kernels on the stream it launches on (at most max_steps calls
+ * are recorded, no call blocks).  ranenv_profile_end waits for the recorded events and returns the
+ * average duration in ms of {allocation kernel, core kernel, head kernel} over n_steps calls. */
+int ranenv_profile_begin(ranenv_handle h, int32_t max_steps);
+int ranenv_profile_end(ranenv_handle h, double *avg_ms3, int32_t *n_steps);
 
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 

@@ -11,15 +11,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranenv_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
 INTRA_RR, INTRA_PF, INTRA_MT, INTRA_PER_SLICE = 0, 1, 2, 255
-F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT = 0x1, 0x2
+F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK = 0x1, 0x2, 0x4
 
 EXPORTS = (
     "ranenv_last_error", "ranenv_abi_version", "ranenv_create", "ranenv_destroy",
     "ranenv_load_scenarios", "ranenv_bind_se_pool", "ranenv_bind_traffic_pool", "ranenv_set_episodes",
-    "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_step_profiled",
+    "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_profile_begin", "ranenv_profile_end",
     "ranenv_get_views",
     "ranenv_launch_info", "ranenv_se_from_power", "ranenv_bind_head_outputs", "ranenv_set_slice_usecase",
 )
@@ -103,7 +103,8 @@ def load() -> C.CDLL:
     lib.ranenv_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ranenv_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.ranenv_step_dense.argtypes = [C.c_void_p] + [C.c_void_p] * 8
-    lib.ranenv_step_profiled.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
+    lib.ranenv_profile_begin.argtypes = [C.c_void_p, C.c_int32]
+    lib.ranenv_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.ranenv_get_views.argtypes = [C.c_void_p, C.POINTER(Views)]
     lib.ranenv_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ranenv_se_from_power.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, INTRA_MT, INTRA_PER_SLICE, INTRA_PF, INTRA_RR,
+from ._lib import (F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK, INTRA_MT, INTRA_PER_SLICE, INTRA_PF, INTRA_RR,
                    POLICY_EXTERNAL, POLICY_MAPF, POLICY_MARR, RanEnvError)
 from .scenario import MAX_AGE_CAP_DEFAULT, ScenarioTables
 
@@ -278,11 +278,16 @@ class BatchedRanEnv:
             "buffer_latencies": lat,
         }
 
-    def step_profiled(self):
-        """Diagnostic: one TTI with HIP events around each kernel -> {'alloc','core'} in ms."""
-        ms = (C.c_float * 4)()
-        self._check(self._lib.ranenv_step_profiled(self._h, ms, self._stream()), "ranenv_step_profiled")
-        return {"alloc": ms[0], "core": ms[1]}
+    def profile_begin(self, max_steps: int = 4096):
+        """Record HIP events around every kernel of the following reset/step calls (non-blocking)."""
+        self._check(self._lib.ranenv_profile_begin(self._h, int(max_steps)), "ranenv_profile_begin")
+
+    def profile_end(self) -> Dict[str, float]:
+        """Average kernel durations in ms over the recorded calls: {'alloc','core','head','n_steps'}."""
+        ms = (C.c_double * 3)()
+        n = C.c_int32()
+        self._check(self._lib.ranenv_profile_end(self._h, ms, C.byref(n)), "ranenv_profile_end")
+        return {"alloc": ms[0], "core": ms[1], "head": ms[2], "n_steps": n.value}
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -186,7 +186,10 @@ class MARLCommEnv:
         terminated = ce.step_number >= ce.max_number_steps
         if terminated and ce.save_hist:
             self.save_history()
-        self._association_step()
+        if not terminated:
+            # next TTI's scenario; a replayed ep_N.npz holds exactly max_number_steps rows
+            # (gen_assoc_mult_slice.py:110-119), so the terminal transition must not index one more
+            self._association_step()
         if isinstance(reward, dict):
             term = {k: terminated for k in reward}
             term["__all__"] = terminated

@@ -1,9 +1,9 @@
 // ranenv.hip -- MI355X (gfx950) implementation of the C ABI in include/ranenv.h.
 //
-// One TTI = two kernels, one workgroup per environment each.  alloc: thread = (slice, UE position)
-// slot, turns scores into RB ranges (inter-slice RBG split, intra-slice RR/PF/MT).  core: thread u owns
-// UE u -- it streams UE u's spectral-efficiency row, updates UE u's packet queue and computes UE u's
-// intent drift, all in registers; per-slice means, observation rows and rewards then go through LDS.
+// One TTI = one kernel, one workgroup per environment, thread u owns UE u: the workgroup first turns the
+// scores into RB ranges (inter-slice RBG split by 16 lanes, intra-slice RR/PF/MT by the UEs through LDS
+// rows), then thread u streams UE u's spectral-efficiency row, updates UE u's packet queue and computes
+// UE u's intent drift, all in registers; per-slice means, observation rows and rewards then go through LDS.
 //
 // HBM layout (B envs, S slices, U UEs, R RBs, L = max_age_cap+1, D = hist_depth):
 //   SE pool        float32 [tile][R][U]   RB-major: at RB r the U lanes of a workgroup read U
@@ -43,9 +43,8 @@
 #define DEVFN __device__ __forceinline__
 
 #ifndef RANENV_DIAG
-#define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the core kernel, 6 leaves only the launch of
-                           the alloc kernel, 8 / 9 stamp s_memtime per phase of the alloc / core kernel
-                           (tools/stamps_alloc.py, tools/stamps.py) */
+#define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the step kernel, 9 stamps s_memtime at its
+                           phase boundaries (tools/stamps.py) */
 #endif
 
 namespace {
@@ -298,84 +297,80 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     full = lf + rf; part = lg + rg;
 }
 
-#if RANENV_DIAG == 8   /* diagnostic build: s_memtime of thread 0 of the alloc kernel at phase boundaries; dumped
-                          into policy_scores[e][0..6] at the end (tools/stamps_alloc.py) */
-#define ALLOC_STAMP(k) alloc_tt[k] = __builtin_amdgcn_s_memtime()
-#else
-#define ALLOC_STAMP(k) do { } while (0)
-#endif
-#if RANENV_DIAG == 9   /* diagnostic build: s_memtime of wave 0 / wave 1 at phase boundaries (the counter ticks at
-                          about the shader clock on this part; only ratios are used) */
-#define RANENV_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (k) + 5 * (int)(threadIdx.x >> 6) < p.S) \
-    p.st.policy_scores[(size_t)(p.e0 + blockIdx.x) * p.S + (k) + 5 * (threadIdx.x >> 6)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of thread 0 at up to S phase boundaries of the step
+                          kernel, dumped into policy_scores[e][k] instead of the scores (tools/stamps.py) */
+#define RANENV_STAMP(k) do { if (threadIdx.x == 0 && (k) < p.S) \
+    p.st.policy_scores[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RANENV_STAMP(k) do { } while (0)
 #endif
 
 // =============================================================================================
-// Kernel 1/2  alloc: one workgroup = one env, thread = slot (slice s = tid / 16, UE position tid % 16),
-// blockDim.x = S*16 rounded up to a wave.
-//   Policy  MARR agents/marr.py:40-47, MAPF agents/mapf.py:41-111
-//   Inter   IBSched.action_format agents/ib_sched.py:240-269, scores_to_rbs / round_int_equal_sum
-//           agents/common.py:442-505          (threads 0..15, one per slice)
-//   Intra   round_robin agents/common.py:508-555, proportional_fairness :558-636,
-//           max_throughput :639-701, distribute_rbs_ues :464-478   (16 lanes per slice)
-// Lanes that exchange data through LDS always sit in one wave (threads 0..15 for the inter-slice
-// part, the 16 lanes of a slice for the intra-slice part), so an LDS wait orders them; only the two
-// hand-overs between the parts need a workgroup barrier.
-// Results: rb_start / rb_count by UE (UEs outside every slice keep the 0 written at reset) and
-// policy_scores by slice.
+// The step kernel: one workgroup = one env, thread u owns UE u, roles in sequence
+//   (0) alloc    IBSched.action_format agents/ib_sched.py:223-349 for this TTI (MODE_STEP only):
+//                policy MARR agents/marr.py:40-47 / MAPF agents/mapf.py:41-111 and the inter-slice split
+//                (scores_to_rbs / round_int_equal_sum agents/common.py:442-505) by lanes 0..15 of wave 0
+//                (lane = slice); intra-slice round_robin :508-555 / proportional_fairness :558-636 /
+//                max_throughput :639-701 / distribute_rbs_ues :464-478 by thread = UE, the UEs of a slice
+//                meeting in that slice's LDS rows (indexed by position in the slice).  Everything it
+//                needs from HBM is state the UE role loads anyway; the first SE loads are already in
+//                flight while it runs.
+//   (1) stream   thread = UE: SE row sums in numpy's pairwise order (SeStream / row_sums)
+//   (2) UE step  thread = UE: capacity -> UEs.step -> 10-TTI window -> intent drift
+//                (oracle/ranenv_oracle.c; agents/common.py:68-340)
+//   (3) obs      thread = slice (sorted position), threads 0..15: calculate_slice_ue_obs
+//                agents/common.py:343-378, IBSched.obs_space_format agents/ib_sched.py:91-200,
+//                calculate_reward :206-221 + common.py:381-439, per-env counters
+// The scenario's slice tables are staged in LDS once per workgroup: every role reads them from there.
 // =============================================================================================
-constexpr int ALLOC_NT = GRP * GRP;   // 256
+constexpr int CORE_NT = GRP * GRP;   // 256 = largest U
 
-struct SharedAlloc {
-    double xs[4][GRP];            // cross-slice rows
-    double rows[GRP][2][GRP];     // per-slice rows
-    int rbs[GRP], off[GRP];
+struct SharedCore {
+    double rows[GRP][4][GRP];     // per slice, by UE position: allocation scratch, then drift x3 + mean SE for (3)
+    double xr[4][GRP];            // cross-slice rows
+    double pf[GRP][3];            // param value                     } slice tables of this env's scenario
+    double sf[GRP][2];            // priority, traffic               }
+    int si[GRP][8];               // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
+    int pi[GRP][6];               // (metric, op) x 3
+    int cnt[GRP][GRP];            // RBs of each slot
+    int flg[GRP][GRP];            // buffer-not-empty flag of each slot
+    int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
 };
 
-// The slot's inputs: UE id (-1 = empty slot), UEs of the slice, queue length, buffer size, packet
-// size, packets sent in the window, mean SE; hlen = pushes in the window.
-DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
-                       int ue, int n, int q, int mp, int pk, long long wsent, double sem)
+// Role (0).  Called by every thread of the workgroup (it contains barriers); `have` = this thread's UE is
+// in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
+// in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
+// slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
+DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, int slc, int pos,
+                       int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count)
 {
-#if RANENV_DIAG == 8
-    unsigned long long alloc_tt[8];
-    alloc_tt[0] = 0;
-#endif
-    ALLOC_STAMP(1);
-    auto &xs = sa.xs; auto &rows = sa.rows;
+    auto &xs = sh.xr;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    const int tid = threadIdx.x;
-    const int s = tid / GRP, pos = tid % GRP;
-    const int S = p.S, U = p.U;
-    const int gsh = (tid & 63) & ~(GRP - 1);
+    const int tid = threadIdx.x, S = p.S;
     const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
-    const bool have = ue >= 0;
-    double *ra = rows[s][0], *rb = rows[s][1];
+    const int sl = have ? slc : 0;                 // idle threads read row 0 and write nothing
+    double *r0 = sh.rows[sl][0], *r1 = sh.rows[sl][1], *r2 = sh.rows[sl][2], *r3 = sh.rows[sl][3];
+    int choice = p.fixed_intra;                    // requested now, used after the inter-slice part
+    if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && have) ? (int)p.intra[(size_t)e * S + sl] : RANENV_INTRA_RR;
     const double occ = (double)q / (double)mp;
     const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
-    if (mapf) { ra[pos] = have ? occ : 0.0; rb[pos] = have ? hm : 0.0; }
-
-    // ---- inter role: thread t < 16 is slice t ---------------------------------------------------
-    const int s1 = tid;
-    const bool ok1 = tid < GRP && s1 < S;
-    int active = 0, nues1 = 0, bsize = 1, msg = 1, sorted = 0;
-    if (ok1) {
-        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s1) * 8;
-        active = si[0]; nues1 = si[2]; bsize = si[3]; msg = si[5]; sorted = si[7];
-    }
-    ALLOC_STAMP(2);
+    const bool has_pkts = have && !d_isclose(occ, 0.0);
+    if (have) { r0[pos] = occ; r1[pos] = hm; sh.flg[sl][pos] = has_pkts ? 1 : 0; }
     __syncthreads();
-    ALLOC_STAMP(3);
-    if (tid < WAVE) {            // wave 0; the other waves go straight to the barrier below
+
+    // ---- inter-slice: lane t < 16 of wave 0 is slice t ----------------------------------------------
+    if (tid < WAVE) {            // the other waves go straight to the barrier below
+        const int s1 = tid;
+        const bool ok1 = tid < GRP && s1 < S;
+        int active = 0, nues1 = 0, bsize = 1, msg = 1, sorted = 0;
+        if (ok1) { active = sh.si[s1][0]; nues1 = sh.si[s1][2]; bsize = sh.si[s1][3]; msg = sh.si[s1][5]; sorted = sh.si[s1][7]; }
         double score = -1.0;
         if (mapf) {
             double occ_mb = 0.0, thr_mb = 0.0;
             if (ok1 && active) {
                 const double pkt = (double)msg, bmax = (double)bsize;
-                occ_mb = ((np_sum16_lds(rows[s1][0], nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
-                thr_mb = ((np_sum16_lds(rows[s1][1], nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+                occ_mb = ((np_sum16_lds(sh.rows[s1][0], nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
+                thr_mb = ((np_sum16_lds(sh.rows[s1][1], nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
             }
             if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
             wave_sync();
@@ -395,9 +390,11 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             }
             wave_sync();
         } else if (ok1) {
-            score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);
+            score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);              // marr.py:40-47
         }
+#if RANENV_DIAG != 9
         if (ok1) p.st.policy_scores[(size_t)e * S + s1] = score;
+#endif
         if (tid < GRP) xs[3][s1] = score;
         wave_sync();
         const int T = p.R / p.G;
@@ -413,9 +410,8 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             const double ssum = np_sum16_lds(xs[0], S), asum = (double)row16_sum(ok1 ? active : 0);
             if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
             nzf = my_v != 0.0;
-            // compaction of the non-zero values in slice order (common.py:484-485)
-            // non-zero values move to the front in slice order, the zeros fill the slots behind them: every
-            // slot is written exactly once, so the row needs no clearing pass
+            // compaction of the non-zero values in slice order (common.py:484-485): they move to the front,
+            // the zeros fill the slots behind them: every slot is written exactly once
             const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull), below = (1u << s1) - 1u;
             m_nz = __popc(gm); slot = nzf ? __popc(gm & below) : m_nz + __popc(~gm & below);
             xs[2][slot] = my_v; xs[3][s1] = my_v;
@@ -435,68 +431,74 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             }
             const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
             const int incl = row16_scan(mine);
-            sa.rbs[s1] = mine; sa.off[s1] = incl - mine;
+            sh.rbs[s1] = mine; sh.off[s1] = incl - mine;
         }
     }
-    ALLOC_STAMP(4);
     __syncthreads();
-    ALLOC_STAMP(5);
 
-    // ---- intra-slice: 16 lanes per slice ---------------------------------------------------------
-    const int n_rbs = s < S ? sa.rbs[s] : 0, off = s < S ? sa.off[s] : 0;
-    int choice = p.fixed_intra;
-    if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && s < S) ? (int)p.intra[(size_t)e * S + s] : RANENV_INTRA_RR;
-    const bool has_pkts = have && !d_isclose(occ, 0.0);
+    // ---- intra-slice: thread = UE; a slice's UEs exchange through its rows ---------------------------
+    const int n = have ? sh.si[sl][2] : 0;
+    const int n_rbs = have ? sh.rbs[sl] : 0, off = have ? sh.off[sl] : 0;
     double avail = 0.0;                          // PF / MT path, evaluated by every slice
     if (have) {
-        const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // :573-578
+        const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // common.py:573-578
         const double cap = sem * slice_bw / (double)n;
         const double backlog = occ * (double)mp * (double)pk;
         avail = cap < backlog ? cap : backlog;
+        r0[pos] = avail;                         // (the occupancy row was consumed by the inter-slice part)
     }
-    ra[pos] = avail;
-    wave_sync();
+    __syncthreads();
     double num = avail;                                                            // MT: weights = avail
     if (choice == RANENV_INTRA_PF) {                                               // :584-602
-        double max_avail = ra[0];
+        double max_avail = r0[0];
 #pragma unroll
-        for (int k = 1; k < 16; k++) { const double av = ra[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+        for (int k = 1; k < 16; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
         double snt = hm * (double)pk;
         if (d_isclose(avail, 0.0)) snt = 1.0;
         num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
     }
-    wave_sync();
-    rb[pos] = have ? num : 0.0;
-    wave_sync();
-    const double wsum = np_sum16_lds(rb, n);
+    if (have) r1[pos] = num;
+    __syncthreads();
+    const double wsum = np_sum16_lds(r1, n);
     const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
     const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
+    if (have) r2[pos] = my_val;
+    __syncthreads();
+    unsigned gmv = 0;                            // which positions of the slice hold a non-zero value
+#pragma unroll
+    for (int k = 0; k < 16; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
     const bool nzv = my_val != 0.0;
-    const unsigned gmv = (unsigned)((__ballot(nzv) >> gsh) & 0xffffull);
     const unsigned below = (1u << pos) - 1u;
-    const int m_v = __popc(gmv), slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below);
-    wave_sync();                                                                   // everyone has read rb / ra
-    ra[slot_v] = my_val;                                                           // compaction (:484-485); zeros go behind
-    rb[pos] = my_val;
-    wave_sync();
+    const int m_v = __popc(gmv), slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
+    if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
+    __syncthreads();
+    int prop = 0;
+    if (use_round) {
+        const double tot = np_sum16_lds(r3, m_v);
+        prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
+    }
+    if (have) sh.cnt[sl][pos] = prop;
+    __syncthreads();
     int count = 0;
     if (use_round) {
-        const double tot = np_sum16_lds(ra, m_v);
-        const int prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;            // floor of a value >= 0
-        const int acc = row16_sum(prop);
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += sh.cnt[sl][k];
         const int adj = n_rbs - acc;
         count = prop;
         if (nzv && adj > 0) {
             int rank = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) { const double xk = rb[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+            for (int k = 0; k < 16; k++) { const double xk = r2[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
             count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
         }
     } else {
         // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
-        const bool account = choice == RANENV_INTRA_RR;
-        const unsigned gmr = (unsigned)((__ballot(has_pkts && account) >> gsh) & 0xffffull);
-        int k_sel = __popc(gmr), idx = __popc(gmr & ((1u << pos) - 1u));
+        unsigned gmr = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) gmr |= sh.flg[sl][k] != 0 ? (1u << k) : 0u;
+        if (choice != RANENV_INTRA_RR) gmr = 0u;
+        int k_sel = __popc(gmr), idx = __popc(gmr & below);
         const bool all = (k_sel == 0);
         if (all) { k_sel = n; idx = pos; }
         if (have && (all || has_pkts) && k_sel > 0) {
@@ -504,61 +506,24 @@ DEVFN void alloc_phase(const KP &p, SharedAlloc &sa, int e, int sc, int hlen,
             count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
     }
-    const int incl = row16_scan(count);                                            // :464-478 contiguous ranges
-    if (have) {
-        p.st.rb_start[(size_t)e * U + ue] = off + incl - count;
-        p.st.rb_count[(size_t)e * U + ue] = count;
-    }
-#if RANENV_DIAG == 8
-    ALLOC_STAMP(6);
-    if (tid == 0) for (int k = 1; k < 7 && k < S; k++) p.st.policy_scores[(size_t)e * S + k] = (double)(alloc_tt[k] - alloc_tt[1]);
-#endif
+    __syncthreads();                                                               // every prop was read
+    if (have) sh.cnt[sl][pos] = count;
+    __syncthreads();
+    int before = 0;                                                                // :464-478 contiguous ranges
+#pragma unroll
+    for (int k = 0; k < 16; k++) before += k < pos ? sh.cnt[sl][k] : 0;
+    rb_start = have ? off + before : 0;
+    rb_count = have ? count : 0;
 }
 
-
-__global__ void __launch_bounds__(ALLOC_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) ranenv_alloc_kernel(const KP p)
-{
-    __shared__ SharedAlloc sa;
-    const int e = p.e0 + blockIdx.x, tid = threadIdx.x;
-#if RANENV_DIAG == 6
-    if (p.B > 0) return;       // launch cost only
+#ifdef RANENV_WAVES_PER_EU   /* experiment knob: pin the step kernel's waves per SIMD (register budget) */
+#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
+#else
+#define RANENV_CORE_ATTR
 #endif
-    const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
-    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);
-    // this thread's UE: slot -> UE id from the scenario's slot table, then the UE's state
-    const int NS16 = p.S * GRP;
-    int ue = -1, q = 0, mp = 1, pk = 1; long long wsent = 0; double sem = 0.0;
-    if (tid < NS16) {
-        const size_t ts = (size_t)sc * NS16 + tid;
-        ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; pk = p.tab.slot_pk[ts];
-        if (ue >= 0) {
-            const size_t su = (size_t)e * p.U + ue;
-            q = p.st.queue_pkts[su]; wsent = p.st.win_sent[su]; sem = p.st.se_mean[su];
-        }
-    }
-    const int gsh = (tid & 63) & ~(GRP - 1);
-    const int n = __popc((unsigned)((__ballot(ue >= 0) >> gsh) & 0xffffull));   // UEs of this slice
-    alloc_phase(p, sa, e, sc, hlen, ue, n, q, mp, pk, wsent, sem);
-}
-
-// =============================================================================================
-// Kernel 2/2  core: one workgroup = one env, three roles in sequence
-//   (1) stream   thread = UE: SE row sums in numpy's pairwise order (SeStream / row_sums)
-//   (2) UE step  thread = UE: capacity -> UEs.step -> 10-TTI window -> intent drift
-//                (oracle/ranenv_oracle.c; agents/common.py:68-340); its state loads are issued at
-//                kernel entry and land under the stream
-//   (3) obs      thread = slice (sorted position), threads 0..15: calculate_slice_ue_obs
-//                agents/common.py:343-378, IBSched.obs_space_format agents/ib_sched.py:91-200,
-//                calculate_reward :206-221 + common.py:381-439, per-env counters
-// =============================================================================================
-struct SharedCore {
-    double rows[GRP][4][GRP];     // hand-off (2) -> (3): drift x3, mean SE by [slice][metric][pos]
-    double xr[3][GRP];
-    int cnt[GRP][GRP];            // RBs of each slot
-};
 
 template <int MODE>
-__global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
+__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
     __shared__ SharedCore sh;
     auto &rows = sh.rows; auto &xr = sh.xr;
@@ -582,8 +547,12 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     const int t = (MODE == MODE_RESET) ? 0 : uni(p.st.step_no[e]);
     int hlen = uni(p.st.hist_len[e]);
     const int npush = uni(p.st.n_push[e]);                    // kept in [0, D)
-    const int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[e]);
-    const int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[e]);
+    // a position persisted under an older, longer trace must not index past the current one
+    int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[e]);
+    int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[e]);
+    se_pos = se_pos < ep.se_len ? se_pos : 0;
+    trf_pos = trf_pos < ep.trf_len ? trf_pos : 0;
+    const int hlen_old = hlen;                                // window length the allocation sees
     const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
     if (clear_hist) hlen = 0;
     const int hlen_new = hlen < D ? hlen + 1 : D;
@@ -591,11 +560,8 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     if (p.se_tiles != nullptr) tile = p.se_tiles + (size_t)e * U * R;
     else tile = p.se_pool + (size_t)(ep.se_base + (long long)se_pos) * (size_t)p.se_stride;
 
-    // ---- (1) stream role: issue the SE loads first ------------------------------------------------
-    SeStream se1;
-    se1.init(tile, U, tid < U ? tid : U - 1, R);   // lane = UE: one dword per RB
-
-    // ---- (2) UE role: everything this UE needs, issued now so that it lands under the stream -----
+    // ---- loads, in the order they are needed: memory operations retire in issue order (vmcnt), so what the
+    // allocation waits for (tables, UE state) is issued before the SE tile and does not queue behind it
     const bool act = tid < U;
     const int u = act ? tid : U - 1;
     const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
@@ -603,12 +569,19 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
+    double sem_prev = 0.0;
     if (MODE != MODE_RESET) {
         total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
         front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
     }
     if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
-    if (MODE == MODE_STEP) { rb_start = p.st.rb_start[su]; rb_count = p.st.rb_count[su]; }
+    if (MODE == MODE_STEP) sem_prev = p.st.se_mean[su];
+    // the scenario's slice tables, one element per thread (blockDim >= 8*S), parked in LDS below
+    int st_si = 0, st_pi = 0; double st_pf = 0.0, st_sf = 0.0;
+    if (tid < S * 8) st_si = p.tab.slice_i32[(size_t)sc * S * 8 + tid];
+    if (tid < S * 6) st_pi = p.tab.param_i32[(size_t)sc * S * 6 + tid];
+    if (tid < S * 3) st_pf = p.tab.param_f64[(size_t)sc * S * 3 + tid];
+    if (tid < S * 2) st_sf = p.tab.slice_f64[(size_t)sc * S * 2 + tid];
     int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
     int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
@@ -616,12 +589,28 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     double traffic = 0.0;
     if (MODE != MODE_RESET)
         traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
-    // zero the (2) -> (3) rows
+    asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
+    SeStream se1;
+    se1.init(tile, U, u, R);                       // lane = UE: one dword per RB
+    asm volatile("" ::: "memory");
+    // zero the per-slice rows, park the tables
     for (int i = tid; i < GRP * 4 * GRP; i += (int)blockDim.x) (&rows[0][0][0])[i] = 0.0;
-    for (int i = tid; i < GRP * GRP; i += (int)blockDim.x) (&sh.cnt[0][0])[i] = 0;
+    for (int i = tid; i < GRP * GRP; i += (int)blockDim.x) { (&sh.cnt[0][0])[i] = 0; (&sh.flg[0][0])[i] = 0; }
+    if (tid < S * 8) (&sh.si[0][0])[tid] = st_si;
+    if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi;
+    if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
+    if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
+    __syncthreads();
+    RANENV_STAMP(1);
+
+    // ---- (0) this TTI's allocation --------------------------------------------------------------------
+    if (MODE == MODE_STEP) {
+        alloc_front(p, sh, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
+                    rb_start, rb_count);
+        RANENV_STAMP(2);
+    }
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
-    RANENV_STAMP(1);
     double my_full = 0.0, my_part = 0.0;
     if (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
@@ -638,10 +627,11 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     } else {
         row_sums(se1, R, [](int) { return false; }, my_full, my_part);
     }
-    __syncthreads();        // the (2) -> (3) rows were zeroed above by all threads
+    RANENV_STAMP(3);
+    __syncthreads();        // every thread is done with the allocation's use of the per-slice rows
+    RANENV_STAMP(4);
 
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
-    RANENV_STAMP(2);
     // np.isclose(previous buffer occupancy, 0) (common.py:108-118): occupancy = total / max_pkts.  Exact
     // shortcuts: an empty queue is 0; a queue above 2e-8 * max_pkts is not close to 0; in between, divide.
     bool prev_empty = total == 0;
@@ -651,19 +641,15 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
 #else
     if (act) {
 #endif
-        // slice row for the drift (L2-resident tables): requested first, it lands while the buffer is stepped
+        // slice row for the drift, from the tables parked in LDS
         int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
         int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
         double pv[3] = {0.0, 0.0, 0.0};
         if (slc >= 0) {
-            const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + slc) * 8;
+            const int *si = sh.si[slc];
             has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                pm[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 0];
-                po[k] = p.tab.param_i32[(((size_t)sc * S + slc) * 3 + k) * 2 + 1];
-                pv[k] = p.tab.param_f64[((size_t)sc * S + slc) * 3 + k];
-            }
+            for (int k = 0; k < 3; k++) { pm[k] = sh.pi[slc][2 * k]; po[k] = sh.pi[slc][2 * k + 1]; pv[k] = sh.pf[slc][k]; }
         }
         if (MODE == MODE_DENSE) {
             const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
@@ -732,7 +718,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
 
         p.st.se_mean[su] = se_mean_new;
-        if (MODE != MODE_STEP) { p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count; }
+        p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count;
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
@@ -797,9 +783,9 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
     }
     if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
-    RANENV_STAMP(3);
+    RANENV_STAMP(5);
     __syncthreads();
-    RANENV_STAMP(4);
+    RANENV_STAMP(6);
 #if RANENV_DIAG == 4 || RANENV_DIAG == 5
     if (my_full >= -1.0) return;
 #endif
@@ -812,20 +798,20 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
     int s = 0, active = 0;
     double priority_tab = 0.0;
     if (ok) {
-        s = p.tab.slice_i32[((size_t)sc * S + spos) * 8 + 7];
-        const int32_t *si = p.tab.slice_i32 + ((size_t)sc * S + s) * 8;
+        s = sh.si[spos][7];
+        const int *si = sh.si[s];
         active = si[0];
         const int has_req = si[1], npar = si[6], n = si[2];
         int rbs_s = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) rbs_s += sh.cnt[s][k];
-        priority_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 0];
-        const double traffic_tab = p.tab.slice_f64[((size_t)sc * S + s) * 2 + 1];
+        priority_tab = sh.sf[s][0];
+        const double traffic_tab = sh.sf[s][1];
         if (n > 0 && has_req) {                                                    // common.py:343-378
 #pragma unroll
             for (int qi = 0; qi < 3; qi++) {
                 if (qi < npar) {
-                    const int m = p.tab.param_i32[(((size_t)sc * S + s) * 3 + qi) * 2 + 0];
+                    const int m = sh.pi[s][2 * qi];
                     const double mean = np_sum16_lds(rows[s][m], n) / (double)n;
                     sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
                 }
@@ -912,9 +898,7 @@ __global__ void __launch_bounds__(ALLOC_NT) ranenv_core_kernel(const KP p)
         }
         if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
     }
-#if RANENV_DIAG == 9
-    if (tid == 0 && S > 9) p.st.policy_scores[(size_t)e * S + 9] = (double)__builtin_amdgcn_s_memtime();
-#endif
+    RANENV_STAMP(7);
 }
 
 // =============================================================================================
@@ -949,7 +933,7 @@ DEVFN double np_sum_seq(const double *a, int n)
     return res;
 }
 
-__global__ void __launch_bounds__(ALLOC_NT) ranenv_head_kernel(const KP p)
+__global__ void __launch_bounds__(CORE_NT) ranenv_head_kernel(const KP p)
 {
     __shared__ SharedHead sh;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
@@ -1145,9 +1129,11 @@ struct ranenv {
     bool have_scenarios = false, have_episodes = false;
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
-    int nslot = 0;                              // threads of the alloc kernel (one per slot, whole waves)
-    bool prof_on = false;                       // ranenv_step_profiled: events around each kernel
-    hipEvent_t prof_ev[3] = {};
+    int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
+    // ranenv_profile_begin / _end: HIP events around every kernel of every step, on the caller's stream
+    bool prof_on = false;
+    int prof_cap = 0, prof_n = 0;               // steps the event pool holds / steps recorded
+    std::vector<hipEvent_t> prof_ev;            // [prof_cap][3]: before the step kernel, after it, after the head kernel
     std::string err;
 };
 
@@ -1186,20 +1172,25 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
     return RANENV_OK;
 }
 
-// One TTI of the whole batch on the caller's stream: alloc -> core (reset / dense skip alloc).
+// One TTI of the whole batch on the caller's stream: the step kernel (+ the head kernel when bound).
 template <int MODE>
 hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream)
 {
     kp.e0 = 0;
     const dim3 grid((unsigned)kp.B);
-    hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;       // diagnostic per-kernel timing
+    // per-kernel timing (ranenv_profile_begin): events on the launch stream, read back in ranenv_profile_end
+    hipEvent_t *ev = (h->prof_on && h->prof_n < h->prof_cap) ? &h->prof_ev[(size_t)h->prof_n * 3] : nullptr;
+    const bool head = kp.head_obs || kp.head_reward;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    if (MODE == MODE_STEP) hipLaunchKernelGGL(ranenv_alloc_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[2], stream);
-    if (kp.head_obs || kp.head_reward) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
-    return hipGetLastError();
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    if (head) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
+    if (ev) { (void)hipEventRecord(ev[2], stream); h->prof_n++; }
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return le;
+    // RANENV_F_SYNC_CHECK: surface asynchronous kernel faults at the call that caused them
+    if (h->cfg.flags & RANENV_F_SYNC_CHECK) return hipStreamSynchronize(stream);
+    return hipSuccess;
 }
 
 }  // namespace
@@ -1215,12 +1206,23 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     *out = nullptr;
     if (cfg->abi_version != RANENV_ABI_VERSION) return fail(nullptr, RANENV_E_INVALID, "abi_version %d != %d", cfg->abi_version, RANENV_ABI_VERSION);
     const int S = cfg->n_slices, U = cfg->n_ues, R = cfg->n_rbs, Us = cfg->max_ues_slice;
-    if (cfg->batch < 1 || S < 1 || S > GRP || U < 1 || U > ALLOC_NT || R < 1 || R > 512 || Us < 1 || Us > GRP ||
+    if (cfg->batch < 1 || S < 1 || S > GRP || U < 1 || U > CORE_NT || R < 1 || R > 512 || Us < 1 || Us > GRP ||
         cfg->rbs_per_rbg < 1 || cfg->rbs_per_rbg > R || cfg->hist_depth < 1 || cfg->hist_depth > 64 ||
         cfg->max_age_cap < 1 || cfg->max_age_cap > 65000 || cfg->max_steps < 1 || cfg->n_scenarios < 1)
         return fail(nullptr, RANENV_E_INVALID,
                     "unsupported sizes: need 1<=S<=16, 1<=U<=256, 1<=R<=512, 1<=Us<=16, 1<=G<=R, 1<=hist_depth<=64");
     if (!(cfg->bandwidth_hz > 0.0)) return fail(nullptr, RANENV_E_INVALID, "bandwidth_hz must be positive");
+    if (R > 128) {   // the row reduction follows numpy's pairwise split two levels deep: every leaf must be <= 128 RBs
+        int n2 = R / 2; n2 -= n2 % 8;
+        const int halves[2] = {n2, R - n2};
+        for (int k = 0; k < 2; k++) {
+            int a = halves[k], b = 0;
+            if (a > 128) { int hh = a / 2; hh -= hh % 8; b = a - hh; a = hh; }
+            if (a > 128 || b > 128)
+                return fail(nullptr, RANENV_E_INVALID, "n_rbs %d needs a third level of numpy's pairwise split (a leaf of %d RBs): "
+                            "supported are R <= 488 and the R in [489,512] whose quarters stay <= 128", R, a > b ? a : b);
+        }
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, RANENV_E_HIP, "no HIP device: %s", hipGetErrorString(e));
@@ -1263,11 +1265,12 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
-    h->nt = (U + WAVE - 1) / WAVE * WAVE;               // core kernel: one lane per UE, at least the 16 slice lanes
-    h->nslot = (S * GRP + WAVE - 1) / WAVE * WAVE;      // alloc kernel: one lane per slot
+    h->nt = (U + WAVE - 1) / WAVE * WAVE;               // step kernel: one lane per UE ...
+    if (h->nt < (S * 8 + WAVE - 1) / WAVE * WAVE) h->nt = (S * 8 + WAVE - 1) / WAVE * WAVE;   // ... and per slice-table word
+    h->nslot = (S * GRP + WAVE - 1) / WAVE * WAVE;      // head kernel: one lane per slot
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
-        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_alloc_kernel));
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP>));
         if (e != hipSuccess) {
             ranenv_destroy(h);
             return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
@@ -1474,25 +1477,38 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     return RANENV_OK;
 }
 
-int ranenv_step_profiled(ranenv_handle h, float *ms3, void *stream_)
+int ranenv_profile_begin(ranenv_handle h, int32_t max_steps)
 {
-    if (!h || !ms3) return fail(h, RANENV_E_INVALID, "null argument");
-    int rc = check_ready(h, nullptr, nullptr, true);
-    if (rc != RANENV_OK) return rc;
-    if (!h->kp.se_pool || !h->kp.trf_pool || h->kp.policy == RANENV_POLICY_EXTERNAL)
-        return fail(h, RANENV_E_STATE, "ranenv_step_profiled needs bound pools and a device policy");
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (max_steps < 1 || max_steps > (1 << 16)) return fail(h, RANENV_E_INVALID, "max_steps must be in [1, 65536]");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    for (auto &e : h->prof_ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
-    hipStream_t stream = (hipStream_t)stream_;
-    KP kp = h->kp;
-    kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
-    kp.dense = nullptr; kp.obs_inter = nullptr; kp.obs_intra = nullptr; kp.reward = nullptr; kp.done = nullptr;
-    h->prof_on = true;
-    const hipError_t le = launch<MODE_STEP>(h, kp, stream);
+    while ((int)h->prof_ev.size() < max_steps * 3) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(h, hipEventCreate(&e));
+        h->prof_ev.push_back(e);
+    }
+    h->prof_cap = max_steps; h->prof_n = 0; h->prof_on = true;
+    return RANENV_OK;
+}
+
+int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps)
+{
+    if (!h || !avg_ms2 || !n_steps) return fail(h, RANENV_E_INVALID, "null argument");
+    if (!h->prof_on) return fail(h, RANENV_E_STATE, "ranenv_profile_begin was not called");
     h->prof_on = false;
-    HIP_TRY(h, le);
-    HIP_TRY(h, hipEventSynchronize(h->prof_ev[2]));
-    for (int k = 0; k < 2; k++) HIP_TRY(h, hipEventElapsedTime(&ms3[k], h->prof_ev[k], h->prof_ev[k + 1]));
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    double acc[2] = {0.0, 0.0};
+    for (int i = 0; i < h->prof_n; i++) {
+        hipEvent_t *ev = &h->prof_ev[(size_t)i * 3];
+        HIP_TRY(h, hipEventSynchronize(ev[2]));
+        for (int k = 0; k < 2; k++) {
+            float ms = 0.0f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            acc[k] += (double)ms;
+        }
+    }
+    for (int k = 0; k < 2; k++) avg_ms2[k] = h->prof_n > 0 ? acc[k] / (double)h->prof_n : 0.0;
+    *n_steps = h->prof_n;
     return RANENV_OK;
 }
 

@@ -282,8 +282,12 @@ class MultSliceAssociation(Association):
     """
 
     def __init__(self, ues, max_number_ues, max_number_basestations, max_number_slices, rng=None,
-                 root_path: str = ".", generator_mode: bool = True, scenario_name: str = "mult_slice"):
+                 root_path: str = ".", generator_mode: bool = True, slice_req_changed: bool = True,
+                 scenario_name: str = "mult_slice"):
+        # positional order of associations/mult_slice.py:9-20 (the reference defaults generator_mode to
+        # False; the datasets it would replay are download links, so the default here is the generator)
         super().__init__(ues, max_number_ues, max_number_basestations, max_number_slices, rng, root_path)
+        self.slice_req_changed = slice_req_changed
         self.min_number_slices = 3
         self.maximum_number_scenarios = 200
         self.generator_mode = generator_mode
@@ -329,3 +333,62 @@ class MultSliceAssociation(Association):
             u = slice_req[f"slice_{s}"]["ues"]
             self.ues.update_ues(ues, np.repeat(u["buffer_latency"], len(ues)),
                                 np.repeat(u["buffer_size"], len(ues)), np.repeat(u["message_size"], len(ues)))
+
+
+class MultSliceAssociationSeq(MultSliceAssociation):
+    """associations/mult_slice_seq.py:9-46: the ``mult_slice_seq`` sweep -- 100 consecutive episodes replay
+    one association scenario (``ep_{episode // 100}.npz`` of the mult_slice folder) while the channel
+    changes every episode (QuadrigaChannelSeq, channels/quadriga_seq.py:28-39)."""
+
+    def __init__(self, ues, max_number_ues, max_number_basestations, max_number_slices, rng=None,
+                 root_path: str = ".", generator_mode: bool = False, slice_req_changed: bool = True,
+                 scenario_name: str = "mult_slice"):
+        super().__init__(ues, max_number_ues, max_number_basestations, max_number_slices, rng, root_path,
+                         generator_mode, slice_req_changed, scenario_name)
+        self.scenario_name = "mult_slice"          # reads the associations of the mult_slice folder (:33-35)
+        self.channels_per_scenario = 100
+
+    def choose_episode(self, episode_number: int, current_episode: int):
+        episode_to_use = episode_number // self.channels_per_scenario
+        if episode_to_use != current_episode:
+            return episode_to_use, True
+        return 0, False
+
+
+def simple_slice_req() -> dict:
+    """The two toy slice intents SimpleSliceAssociation installs (associations/simple_slice.py:46-105)."""
+    from .scenario import OP_NAME, OP_UFUNC
+    ge, le = OP_UFUNC[OP_NAME["at_least"]], OP_UFUNC[OP_NAME["at_most"]]
+    ues = {"buffer_size": 10, "buffer_latency": 10, "message_size": 1, "mobility": 0, "traffic": 2,
+           "min_number_ues": 8, "max_number_ues": 10}
+    return {
+        "slice_0": {
+            "name": "robotic_surgery_case_1",
+            "parameters": {
+                "par1": {"name": "reliability", "value": 99.00, "unit": "rate", "operator": ge},
+                "par2": {"name": "latency", "value": 20, "unit": "ms", "operator": le},
+                "par3": {"name": "throughput", "value": 1, "unit": "Mbps", "operator": ge},
+            },
+            "ues": dict(ues),
+        },
+        "slice_1": {
+            "name": "control_case_2",
+            "parameters": {
+                "par1": {"name": "reliability", "value": 1.0, "unit": "rate", "operator": ge},
+                "par2": {"name": "latency", "value": 20, "unit": "ms", "operator": le},
+            },
+            "ues": dict(ues),
+        },
+    }
+
+
+class SimpleSliceAssociation(Association):
+    """associations/simple_slice.py:27-112: associations pass through unchanged; at step 0 the two toy
+    slice intents replace ``slice_req`` (the reference never pushes their buffer parameters to the UEs:
+    it has no update_ues call, so the UEs keep what the env was built with)."""
+
+    def step(self, basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req,
+             step_number, episode_number):
+        if step_number == 0:
+            slice_req = simple_slice_req()
+        return basestation_ue_assoc, basestation_slice_assoc, slice_ue_assoc, slice_req

@@ -113,3 +113,64 @@ def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POL
     env.set_policy(policy, intra)
     return Workload(name or f"mult_slice S{n_slices}/U{n_ues}/R{n_rbs} B{batch}", env, tables, se_pool, trf,
                     scenario, se_trace, se_offset, trace_len, policy, intra)
+
+
+def make_mult_slice_seq_workload(batch: int, device: torch.device, policy: int = POLICY_MAPF, intra: int = INTRA_PF,
+                                 n_groups: int = 10, channels_per_scenario: int = 100, n_traces: int = 200,
+                                 trace_len: int = 200, seed: int = 10, n_slices: int = 10, n_ues: int = 100,
+                                 n_rbs: int = 135, rbs_per_rbg: int = 1, max_ues_slice: int = 10,
+                                 max_steps: int = 1000, rank: int = 0, flags: int = 0) -> Workload:
+    """BASELINE configs[4]: the ``mult_slice_seq`` per-scenario sweep.  Env e plays episode number
+    ``rank*batch + e``; like MultSliceAssociationSeq / QuadrigaChannelSeq (associations/mult_slice_seq.py:38-46,
+    channels/quadriga_seq.py:28-39) the association scenario is ``episode // channels_per_scenario`` (mod
+    n_groups) and the channel trace changes with every episode, so the envs of a group share the
+    association row but not the SE trace.  Scenarios carry 3..S active slices with different intent metric
+    sets (the branchy path)."""
+    tables = generate_scaled_scenarios(n_groups, seed=seed, n_slices=n_slices, n_ues=n_ues,
+                                       max_ues_slice=max_ues_slice, min_slices=min(3, n_slices),
+                                       min_ues=min(2, max_ues_slice))
+    env = BatchedRanEnv(batch=batch, n_slices=n_slices, n_ues=n_ues, n_rbs=n_rbs, rbs_per_rbg=rbs_per_rbg,
+                        max_ues_slice=max_ues_slice, n_scenarios=n_groups, max_steps=max_steps,
+                        device=device, flags=flags)
+    env.load_scenarios(tables)
+    se_pool = mimic_quadriga_pool(n_traces, trace_len, n_ues, n_rbs, seed + 1000 * (rank + 1), env.device)
+    trf = torch.from_numpy(poisson_traffic_pool(tables, trace_len, seed + 7)).to(env.device)
+    env.bind_se_pool(se_pool)
+    env.bind_traffic_pool(trf)
+    episode = np.arange(batch, dtype=np.int64) + rank * batch
+    scenario = (episode // channels_per_scenario) % n_groups
+    se_trace = episode % n_traces
+    rng = np.random.default_rng(seed + 31 * (rank + 1))
+    se_offset = rng.integers(0, trace_len, batch)
+    env.set_episodes(scenario=scenario, se_base=se_trace * trace_len, se_len=trace_len, se_offset=se_offset,
+                     trf_base=scenario * trace_len, trf_len=trace_len, trf_offset=rng.integers(0, trace_len, batch))
+    env.set_policy(policy, intra)
+    return Workload(f"mult_slice_seq S{n_slices}/U{n_ues}/R{n_rbs} B{batch}", env, tables, se_pool, trf,
+                    scenario, se_trace, se_offset, trace_len, policy, intra)
+
+
+def make_bench_workload(config: int, device: torch.device, batch: Optional[int] = None, n_traces: int = 200,
+                        trace_len: int = 200, rank: int = 0, traffic: str = "pool"):
+    """The BASELINE.json ``configs[config]`` workload for one rank -> (Workload, label)."""
+    if config == 1:
+        wl = make_mult_slice_workload(batch or 1024, device, policy=POLICY_MARR, intra=INTRA_RR, n_traces=n_traces,
+                                      trace_len=trace_len, rank=rank)
+        label = ("mult_slice, 10 slices, 100 UEs, 135 RBGs, MARR inter-slice + round-robin intra-slice + ib_sched "
+                 "intent observation/reward")
+    elif config in (2, 3):
+        wl = make_mult_slice_workload(batch or 4096, device, policy=POLICY_MAPF, intra=INTRA_PF, n_traces=n_traces,
+                                      trace_len=trace_len, rank=rank)
+        label = ("mult_slice, 10 slices, 100 UEs, 135 RBGs, MAPF inter-slice + PF intra-slice + ib_sched intent "
+                 "observation/reward")
+    elif config == 4:
+        wl = make_mult_slice_seq_workload(batch or 8192, device, policy=POLICY_MAPF, intra=INTRA_PF,
+                                          n_traces=n_traces, trace_len=trace_len, rank=rank)
+        label = ("mult_slice_seq per-scenario sweep, 10 scenario groups with 3..10 active slices (mixed masks and "
+                 "intent metric sets), 100 UEs, 135 RBGs, MAPF + PF + ib_sched intent observation/reward")
+    else:
+        raise ValueError(f"no bench workload for BASELINE configs[{config}]")
+    if traffic == "philox":
+        wl.env.set_traffic_generator(seed=1234 + rank)
+    elif traffic != "pool":
+        raise ValueError("traffic must be 'pool' or 'philox'")
+    return wl, label

@@ -107,6 +107,17 @@ def sort_slices(nues: np.ndarray, traffic: np.ndarray, has_req: np.ndarray) -> n
     return out
 
 
+def quadriga_se_from_power(target_cell_power: np.ndarray, n_rbs: int, transmission_power: float = 100.0,
+                           thermal_noise_power: float = 10e-14) -> np.ndarray:
+    """Checker for the channel-ingest kernel (ranenv_se_from_power): QuadrigaChannel.step's transform,
+    channels/quadriga.py:56-69 -- ``spectral_efficiencies = log2(1 + (transmission_power / num_available_rbs)
+    * target_cell_power / (intercell_interference + thermal_noise_power))`` with intercell_interference an
+    all-zeros array (:62-66), float64 numpy, elementwise."""
+    g = np.asarray(target_cell_power, dtype=np.float64)
+    interference = np.zeros(g.shape)
+    return np.log2(1 + np.divide((transmission_power / n_rbs) * g, interference + thermal_noise_power))
+
+
 def make_cfg(S, U, R, G, Us, bandwidth_hz=100e6, hist_depth=10, max_age_cap=400, max_steps=1000,
              overfulfill=0.2, norm_traffic=120.0, norm_ues=5.0, norm_se=40.0) -> _Cfg:
     return _Cfg(S, U, R, G, Us, hist_depth, max_age_cap, max_steps, bandwidth_hz, overfulfill,

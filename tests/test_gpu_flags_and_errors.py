@@ -160,7 +160,7 @@ def test_se_from_power_matches_the_reference_formula():
     log2 may differ from numpy's in the last float64 bit, so the float32 results are allowed to differ by one
     float32 ulp in rare rounding ties; everything else must be identical."""
     _need_gpu()
-    from intent_radio_sched_multi_slice_amd.plugins import quadriga_se_from_power
+    from oracle.pyoracle import quadriga_se_from_power          # the checker lives on the oracle side of the wall
     from intent_radio_sched_multi_slice_amd.workloads import quadriga_pool_from_power
     rng = np.random.default_rng(5)
     for shape in ((7, 135, 100), (3, 25, 4), (1, 1, 1), (5, 33, 7)):

@@ -1,14 +1,24 @@
-"""A/B of two builds on one box: python tools/abprobe.py libA.so libB.so  (each run in its own process, interleaved)"""
+"""A/B of builds on one box: python tools/abprobe.py [--config N] libA.so libB.so ...  (each run in its own process, interleaved)"""
 import subprocess, sys, os, re
-libs = sys.argv[1:]
+args = sys.argv[1:]
+config = "2"
+if args and args[0] == "--config":
+    config = args[1]; args = args[2:]
+libs = args
 res = {l: [] for l in libs}
-for rep in range(4):
+for rep in range(3):
     for l in libs:
-        env = dict(os.environ, RANENV_LIB=l)
-        out = subprocess.run([sys.executable, "tools/benchprobe.py"], env=env, capture_output=True, text=True).stdout
-        m = re.search(r"step\s+([\d.]+) us\s+alloc\s+([\d.]+)\s+core\s+([\d.]+)", out)
+        env = dict(os.environ)
+        if l != "default":
+            env["RANENV_LIB"] = os.path.abspath(l)
+        out = subprocess.run([sys.executable, "tools/benchprobe.py", config], env=env, capture_output=True, text=True)
+        m = re.search(r"step\s+([\d.]+) us\s+kernel\s+([\d.]+)", out.stdout)
+        if not m:
+            print(l, "FAILED", out.stdout[-300:], out.stderr[-600:], flush=True)
+            continue
         res[l].append(tuple(float(x) for x in m.groups()))
         print(l, res[l][-1], flush=True)
 for l in libs:
     a = res[l]
-    print(f"{l:28s} step {sum(x[0] for x in a) / len(a):6.1f}  alloc {sum(x[1] for x in a) / len(a):5.1f}  core {sum(x[2] for x in a) / len(a):5.1f}")
+    if a:
+        print(f"{l:32s} step {sum(x[0] for x in a) / len(a):6.1f}  kernel {sum(x[1] for x in a) / len(a):6.1f}   (min step {min(x[0] for x in a):.1f})")

@@ -1,10 +1,12 @@
-"""Per-kernel time on the bench workload (big SE pool, no cache reuse): python tools/benchprobe.py"""
+"""Step time on the bench workload (big SE pool, no cache reuse): python tools/benchprobe.py [config] [batch]
+RANENV_LIB selects the build.  Prints the device time per TTI over 300 steps and the per-kernel event average."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from intent_radio_sched_multi_slice_amd import _lib
-from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
-wl = make_mult_slice_workload(4096, torch.device("cuda", 0), policy=_lib.POLICY_MAPF, intra=_lib.INTRA_PF, n_traces=200, trace_len=200)
+import torch
+from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else None
+wl, _ = make_bench_workload(config, torch.device("cuda", 0), batch=batch)
 env = wl.env
 env.reset()
 for _ in range(30):
@@ -16,6 +18,8 @@ e0.record()
 for _ in range(K):
     env.step()
 e1.record(); torch.cuda.synchronize()
-r = [env.step_profiled() for _ in range(40)]
-a = np.array([x["alloc"] for x in r]) * 1e3; c = np.array([x["core"] for x in r]) * 1e3
-print(f"PF_KB={os.environ.get('RANENV_PF_KB', '0'):3s} step {e0.elapsed_time(e1) / K * 1e3:6.1f} us   alloc {np.median(a):5.1f}   core {np.median(c):5.1f}", flush=True)
+env.profile_begin(100)
+for _ in range(100):
+    env.step()
+k = env.profile_end()
+print(f"{os.path.basename(os.environ.get('RANENV_LIB', 'default')):14s} cfg {config} step {e0.elapsed_time(e1) / K * 1e3:6.1f} us   kernel {k['core'] * 1e3:6.1f}", flush=True)
