@@ -105,7 +105,7 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed
     achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9            # per-GPU GB/s on the wall clock
     dev_ms = sum(v for k, v in kernel_ms.items() if k != "n_steps")
     dom = max((k for k in kernel_ms if k != "n_steps"), key=lambda k: kernel_ms[k])
-    dom_bytes = alg_bytes if kernel_ms.get("alloc", 0.0) == 0.0 else (alg_bytes_env_step - S * 5) * batch
+    dom_bytes = alg_bytes                                       # one kernel does the whole TTI
     dom_gbs = dom_bytes / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
     return {
         "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling",
@@ -127,7 +127,8 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed
                      "frac_device": (alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms > 0 else None,
                      "kernels_ms": {k: v for k, v in kernel_ms.items() if k != "n_steps"},
                      "kernels_ms_source": f"HIP events on the launch stream around each kernel, {kernel_ms.get('n_steps', 0)} "
-                                          "steps repeated right after the timed region",
+                                          "steps repeated right after the timed region, each step waited for (a kernel "
+                                          "timed alone, as rocprofv3 --kernel-trace times it)",
                      "dominant_kernel": {"name": dom, "ms": kernel_ms[dom], "algorithmic_bytes": dom_bytes,
                                          "achieved": dom_gbs, "frac": dom_gbs / HBM_PEAK_GBS}},
         "metrics": metrics,
@@ -191,11 +192,11 @@ def main():
     # metrics: the only collective, once per reporting interval, outside the timed K steps
     gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, args.steps))
     # the same K steps again with HIP events around every kernel (on the stream they are launched on)
-    env.profile_begin(args.steps)
+    env.profile_begin()
     for _ in range(args.steps):
         env.step()
     kms = env.profile_end()
-    kernel_ms = {"alloc": kms["alloc"], "core": kms["core"], "n_steps": kms["n_steps"]}
+    kernel_ms = {"ranenv_core_kernel<STEP>": kms["step"], "n_steps": kms["n_steps"]}
 
     if rank == 0:
         traffic = None

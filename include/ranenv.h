@@ -201,12 +201,12 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
 
-/* Per-kernel timing of ordinary steps: after ranenv_profile_begin every reset / step / step_dense call
- * records HIP events around each of its kernels on the stream it launches on (at most max_steps calls
- * are recorded, no call blocks).  ranenv_profile_end waits for the recorded events and returns the
- * average duration in ms of {allocation kernel, core kernel, head kernel} over n_steps calls. */
-int ranenv_profile_begin(ranenv_handle h, int32_t max_steps);
-int ranenv_profile_end(ranenv_handle h, double *avg_ms3, int32_t *n_steps);
+/* Per-kernel timing of ordinary steps: between ranenv_profile_begin and ranenv_profile_end every reset / step /
+ * step_dense call records HIP events around each of its kernels on the stream it launches on and waits for them
+ * (a profiled step runs alone on the device, as under rocprofv3).  ranenv_profile_end returns the average duration
+ * in ms of {step kernel, head kernel} over the n_steps profiled calls. */
+int ranenv_profile_begin(ranenv_handle h);
+int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps);
 
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 

@@ -103,7 +103,7 @@ def load() -> C.CDLL:
     lib.ranenv_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ranenv_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.ranenv_step_dense.argtypes = [C.c_void_p] + [C.c_void_p] * 8
-    lib.ranenv_profile_begin.argtypes = [C.c_void_p, C.c_int32]
+    lib.ranenv_profile_begin.argtypes = [C.c_void_p]
     lib.ranenv_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.ranenv_get_views.argtypes = [C.c_void_p, C.POINTER(Views)]
     lib.ranenv_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

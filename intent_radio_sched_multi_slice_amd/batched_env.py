@@ -278,16 +278,16 @@ class BatchedRanEnv:
             "buffer_latencies": lat,
         }
 
-    def profile_begin(self, max_steps: int = 4096):
-        """Record HIP events around every kernel of the following reset/step calls (non-blocking)."""
-        self._check(self._lib.ranenv_profile_begin(self._h, int(max_steps)), "ranenv_profile_begin")
+    def profile_begin(self):
+        """Time every kernel of the following reset/step calls with HIP events (each profiled call waits for its kernels)."""
+        self._check(self._lib.ranenv_profile_begin(self._h), "ranenv_profile_begin")
 
     def profile_end(self) -> Dict[str, float]:
-        """Average kernel durations in ms over the recorded calls: {'alloc','core','head','n_steps'}."""
-        ms = (C.c_double * 3)()
+        """Average kernel durations in ms over the profiled calls: {'step','head','n_steps'}."""
+        ms = (C.c_double * 2)()
         n = C.c_int32()
         self._check(self._lib.ranenv_profile_end(self._h, ms, C.byref(n)), "ranenv_profile_end")
-        return {"alloc": ms[0], "core": ms[1], "head": ms[2], "n_steps": n.value}
+        return {"step": ms[0], "head": ms[1], "n_steps": n.value}
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -72,11 +72,17 @@ struct State {
     int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
     int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
+    // allocation made at the end of a step for the next one (device policy): valid while alloc_gen[e] == KP::alloc_gen
+    int32_t *alloc_gen, *next_rb_start, *next_rb_count; double *next_scores;
 };
 
 struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
     int e0;   // first env of this launch
+    int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
+    int late;        // 0: every step allocates at its head; 1: a hashed half of the envs, 2: all envs allocate for the next
+                     // TTI at the end of the step (device policy only), so that heads and tails of workgroups differ in
+                     // what they load the CU with
     double bw_hz, bw_per_rb, over, norm_traffic, norm_ues, norm_se;
     Tables tab;
     State st;
@@ -194,7 +200,10 @@ DEVFN RowPlan make_row_plan(int n)
 }
 
 #ifndef RANENV_SE_DEPTH
-#define RANENV_SE_DEPTH 3
+#define RANENV_SE_DEPTH 2
+#endif
+#ifndef RANENV_LATE_DEFAULT
+#define RANENV_LATE_DEFAULT 1
 #endif
 constexpr int SE_NQ = RANENV_SE_DEPTH;   // 8-row groups in flight per lane
 
@@ -342,7 +351,7 @@ struct SharedCore {
 // in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
 // slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
 DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, int slc, int pos,
-                       int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count)
+                       int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out)
 {
     auto &xs = sh.xr;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
@@ -393,7 +402,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);              // marr.py:40-47
         }
 #if RANENV_DIAG != 9
-        if (ok1) p.st.policy_scores[(size_t)e * S + s1] = score;
+        if (ok1) scores_out[(size_t)e * S + s1] = score;
 #endif
         if (tid < GRP) xs[3][s1] = score;
         wave_sync();
@@ -516,11 +525,10 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     rb_count = have ? count : 0;
 }
 
-#ifdef RANENV_WAVES_PER_EU   /* experiment knob: pin the step kernel's waves per SIMD (register budget) */
-#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
-#else
-#define RANENV_CORE_ATTR
+#ifndef RANENV_WAVES_PER_EU   /* waves per SIMD the step kernel is compiled for: 4 = 128 VGPRs, 8 workgroups of 2 waves per CU */
+#define RANENV_WAVES_PER_EU 4
 #endif
+#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
 
 template <int MODE>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
@@ -582,6 +590,15 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     if (tid < S * 6) st_pi = p.tab.param_i32[(size_t)sc * S * 6 + tid];
     if (tid < S * 3) st_pf = p.tab.param_f64[(size_t)sc * S * 3 + tid];
     if (tid < S * 2) st_sf = p.tab.slice_f64[(size_t)sc * S * 2 + tid];
+    // device policy: this TTI's allocation may have been made at the end of the previous step
+    bool pre = false;
+    if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(p.st.alloc_gen[e]) == p.alloc_gen;
+    if (pre) {
+        rb_start = p.st.next_rb_start[su]; rb_count = p.st.next_rb_count[su];
+#if RANENV_DIAG != 9
+        if (tid < S) p.st.policy_scores[(size_t)e * S + tid] = p.st.next_scores[(size_t)e * S + tid];
+#endif
+    }
     int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
     int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
@@ -604,11 +621,10 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     RANENV_STAMP(1);
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
-    if (MODE == MODE_STEP) {
+    if (MODE == MODE_STEP && !pre)
         alloc_front(p, sh, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
-                    rb_start, rb_count);
-        RANENV_STAMP(2);
-    }
+                    rb_start, rb_count, p.st.policy_scores);
+    RANENV_STAMP(2);
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
     double my_full = 0.0, my_part = 0.0;
@@ -634,6 +650,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
     // np.isclose(previous buffer occupancy, 0) (common.py:108-118): occupancy = total / max_pkts.  Exact
     // shortcuts: an empty queue is 0; a queue above 2e-8 * max_pkts is not close to 0; in between, divide.
+    double sem_new = 0.0;
     bool prev_empty = total == 0;
     if (total != 0 && !((double)total > 2e-8 * (double)max_pkts)) prev_empty = d_isclose((double)total / (double)max_pkts, 0.0);
 #if RANENV_DIAG == 3 || RANENV_DIAG == 5
@@ -717,7 +734,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
             p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
         }
 
-        p.st.se_mean[su] = se_mean_new;
+        p.st.se_mean[su] = se_mean_new; sem_new = se_mean_new;
         p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count;
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
@@ -789,7 +806,8 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
 #if RANENV_DIAG == 4 || RANENV_DIAG == 5
     if (my_full >= -1.0) return;
 #endif
-    if (tid >= GRP) return;                  // (3) is done by threads 0..15 (one wave)
+    do {
+    if (tid >= GRP) break;                   // (3) is done by threads 0..15 (one wave)
 
     // ---- thread t < 16: slice at sorted position t (ib_sched.py:91) --------------------------------
     const int spos = tid;
@@ -898,7 +916,21 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         }
         if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
     }
+    } while (0);
     RANENV_STAMP(7);
+
+    // ---- (0') the next TTI's allocation, from the state this step leaves behind ----------------------
+    bool late = false;
+    if (MODE == MODE_STEP) late = p.scores == nullptr && (p.late == 2 || (p.late == 1 && (((unsigned)e * 0x9E3779B1u) >> 16 & 1u)));
+    if (late) {
+        __syncthreads();                     // (3) is done with the per-slice rows
+        int ns = 0, nc = 0;
+        alloc_front(p, sh, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
+                    ns, nc, p.st.next_scores);
+        if (act) { p.st.next_rb_start[su] = ns; p.st.next_rb_count[su] = nc; }
+    }
+    if (tid == 0) p.st.alloc_gen[e] = late ? p.alloc_gen : 0;
+    RANENV_STAMP(8);
 }
 
 // =============================================================================================
@@ -1127,13 +1159,15 @@ struct ranenv {
     std::vector<void *> allocs;
     ranenv_episode *d_episodes = nullptr;
     bool have_scenarios = false, have_episodes = false;
+    int alloc_gen = 1;                          // bumped by everything a stored next-TTI allocation depends on
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
     // ranenv_profile_begin / _end: HIP events around every kernel of every step, on the caller's stream
     bool prof_on = false;
-    int prof_cap = 0, prof_n = 0;               // steps the event pool holds / steps recorded
-    std::vector<hipEvent_t> prof_ev;            // [prof_cap][3]: before the step kernel, after it, after the head kernel
+    int prof_n = 0;                             // steps recorded
+    double prof_ms[2] = {0.0, 0.0};             // summed durations: step kernel, head kernel
+    hipEvent_t prof_ev[3] = {};                 // before the step kernel, after it, after the head kernel
     std::string err;
 };
 
@@ -1176,18 +1210,30 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
 template <int MODE>
 hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream)
 {
-    kp.e0 = 0;
+    kp.e0 = 0; kp.alloc_gen = h->alloc_gen;
     const dim3 grid((unsigned)kp.B);
-    // per-kernel timing (ranenv_profile_begin): events on the launch stream, read back in ranenv_profile_end
-    hipEvent_t *ev = (h->prof_on && h->prof_n < h->prof_cap) ? &h->prof_ev[(size_t)h->prof_n * 3] : nullptr;
+    // per-kernel timing (ranenv_profile_begin): events on the launch stream around each kernel.  The call waits for
+    // its kernels: with further launches queued behind, the runtime's event timestamps bracket the gap between
+    // kernels rather than the kernel (measured), so a profiled step is timed alone, as rocprofv3 times it.
+    hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;
     const bool head = kp.head_obs || kp.head_reward;
     if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (head) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
-    if (ev) { (void)hipEventRecord(ev[2], stream); h->prof_n++; }
+    if (ev) (void)hipEventRecord(ev[2], stream);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return le;
+    if (ev) {
+        hipError_t pe = hipEventSynchronize(ev[2]);
+        for (int k = 0; k < 2 && pe == hipSuccess; k++) {
+            float ms = 0.0f;
+            pe = hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+            h->prof_ms[k] += (double)ms;
+        }
+        if (pe != hipSuccess) return pe;
+        h->prof_n++;
+    }
     // RANENV_F_SYNC_CHECK: surface asynchronous kernel faults at the call that caused them
     if (h->cfg.flags & RANENV_F_SYNC_CHECK) return hipStreamSynchronize(stream);
     return hipSuccess;
@@ -1238,6 +1284,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.B = cfg->batch; kp.S = S; kp.U = U; kp.R = R; kp.G = cfg->rbs_per_rbg; kp.Us = Us; kp.D = cfg->hist_depth;
     kp.L = (int)L; kp.max_steps = cfg->max_steps; kp.flags = cfg->flags;
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
+    kp.late = RANENV_LATE_DEFAULT;
+    if (const char *lv = getenv("RANENV_LATE")) kp.late = atoi(lv) < 0 ? 0 : (atoi(lv) > 2 ? 2 : atoi(lv));   // experiment knob
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
     kp.norm_traffic = cfg->norm_traffic; kp.norm_ues = cfg->norm_ues; kp.norm_se = cfg->norm_se;
     int rc = RANENV_OK;
@@ -1256,6 +1304,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.st.pkt_incoming, B * U); ALLOC(kp.st.pkt_throughputs, B * U); ALLOC(kp.st.pkt_effective_thr, B * U);
     ALLOC(kp.st.dropped_pkts, B * U); ALLOC(kp.st.rb_start, B * U); ALLOC(kp.st.rb_count, B * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
+    ALLOC(kp.st.alloc_gen, B); ALLOC(kp.st.next_rb_start, B * U); ALLOC(kp.st.next_rb_count, B * U); ALLOC(kp.st.next_scores, B * S);
     {
         const size_t NSL = (size_t)S * GRP;
         ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
@@ -1364,7 +1413,7 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     PUT(d.slot_pk + f * NSL, spk.data(), n * NSL, int32_t);
 #undef PUT
     HIP_TRY(h, hipStreamSynchronize(stream));  // staging vectors die at return
-    h->have_scenarios = true;
+    h->have_scenarios = true; h->alloc_gen++;
     return RANENV_OK;
 }
 
@@ -1409,7 +1458,7 @@ int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *eps, void *stream
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(h->d_episodes, eps, sizeof(ranenv_episode) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
-    h->have_episodes = true;
+    h->have_episodes = true; h->alloc_gen++;
     return RANENV_OK;
 }
 
@@ -1419,7 +1468,7 @@ int ranenv_set_policy(ranenv_handle h, int32_t policy, int32_t fixed_intra)
     if (policy < RANENV_POLICY_EXTERNAL || policy > RANENV_POLICY_MAPF) return fail(h, RANENV_E_INVALID, "unknown policy %d", policy);
     if (!(fixed_intra == RANENV_INTRA_RR || fixed_intra == RANENV_INTRA_PF || fixed_intra == RANENV_INTRA_MT || fixed_intra == RANENV_INTRA_PER_SLICE))
         return fail(h, RANENV_E_INVALID, "unknown intra-slice scheduler %d", fixed_intra);
-    h->kp.policy = policy; h->kp.fixed_intra = fixed_intra;
+    h->kp.policy = policy; h->kp.fixed_intra = fixed_intra; h->alloc_gen++;
     return RANENV_OK;
 }
 
@@ -1477,17 +1526,12 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     return RANENV_OK;
 }
 
-int ranenv_profile_begin(ranenv_handle h, int32_t max_steps)
+int ranenv_profile_begin(ranenv_handle h)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
-    if (max_steps < 1 || max_steps > (1 << 16)) return fail(h, RANENV_E_INVALID, "max_steps must be in [1, 65536]");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    while ((int)h->prof_ev.size() < max_steps * 3) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(h, hipEventCreate(&e));
-        h->prof_ev.push_back(e);
-    }
-    h->prof_cap = max_steps; h->prof_n = 0; h->prof_on = true;
+    for (auto &e : h->prof_ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
+    h->prof_n = 0; h->prof_ms[0] = h->prof_ms[1] = 0.0; h->prof_on = true;
     return RANENV_OK;
 }
 
@@ -1496,18 +1540,7 @@ int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps)
     if (!h || !avg_ms2 || !n_steps) return fail(h, RANENV_E_INVALID, "null argument");
     if (!h->prof_on) return fail(h, RANENV_E_STATE, "ranenv_profile_begin was not called");
     h->prof_on = false;
-    HIP_TRY(h, hipSetDevice(h->cfg.device));
-    double acc[2] = {0.0, 0.0};
-    for (int i = 0; i < h->prof_n; i++) {
-        hipEvent_t *ev = &h->prof_ev[(size_t)i * 3];
-        HIP_TRY(h, hipEventSynchronize(ev[2]));
-        for (int k = 0; k < 2; k++) {
-            float ms = 0.0f;
-            HIP_TRY(h, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-            acc[k] += (double)ms;
-        }
-    }
-    for (int k = 0; k < 2; k++) avg_ms2[k] = h->prof_n > 0 ? acc[k] / (double)h->prof_n : 0.0;
+    for (int k = 0; k < 2; k++) avg_ms2[k] = h->prof_n > 0 ? h->prof_ms[k] / (double)h->prof_n : 0.0;
     *n_steps = h->prof_n;
     return RANENV_OK;
 }

@@ -9,8 +9,12 @@ res = {l: [] for l in libs}
 for rep in range(3):
     for l in libs:
         env = dict(os.environ)
-        if l != "default":
-            env["RANENV_LIB"] = os.path.abspath(l)
+        lib, _, knobs = l.partition("@")          # lib.so@LATE=2,FOO=1 sets experiment env vars RANENV_LATE, RANENV_FOO
+        for kv in filter(None, knobs.split(",")):
+            k, _, v = kv.partition("=")
+            env["RANENV_" + k] = v
+        if lib != "default":
+            env["RANENV_LIB"] = os.path.abspath(lib)
         out = subprocess.run([sys.executable, "tools/benchprobe.py", config], env=env, capture_output=True, text=True)
         m = re.search(r"step\s+([\d.]+) us\s+kernel\s+([\d.]+)", out.stdout)
         if not m:
