@@ -89,6 +89,8 @@ class BatchedRanEnv:
         self._obs_dict = {"obs_inter": self.obs_inter, "obs_intra": self.obs_intra}
         self._p_out = (_ptr(self.obs_inter), _ptr(self.obs_intra), _ptr(self.reward), _ptr(self.done))
         self._step_fn = self._lib.ranenv_step
+        self.policy, self.fixed_intra = POLICY_MARR, INTRA_RR      # the library's defaults (ranenv_create)
+        self._recorder = None
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -172,6 +174,21 @@ class BatchedRanEnv:
 
     def set_policy(self, policy: int = POLICY_EXTERNAL, fixed_intra: int = INTRA_PER_SLICE):
         self._check(self._lib.ranenv_set_policy(self._h, int(policy), int(fixed_intra)), "ranenv_set_policy")
+        self.policy, self.fixed_intra = int(policy), int(fixed_intra)
+
+    def record(self, envs, root_path: str = ".", simu_name: str = "mult_slice", agent_name: str = "agent",
+               episode_numbers=None, marl: bool = True):
+        """Keep the traces of the listed envs on the device and write ``hist/{simu_name}/{agent_name}/ep_{n}.npz``
+        (the 16 keys of results/gen_results.py:88-108) whenever one of them reports ``done``.  ``record(None)``
+        stops recording.  Returns the recorder (``.written`` lists the files)."""
+        if envs is None:
+            self._recorder = None
+            return None
+        from .history import HistoryRecorder
+        if self.tables is None or self.episodes is None:
+            raise RanEnvError("record() needs load_scenarios + set_episodes first")
+        self._recorder = HistoryRecorder(self, envs, root_path, simu_name, agent_name, episode_numbers, marl)
+        return self._recorder
 
     # ------------------------------------------------------------------------------------------
     def _obs(self):
@@ -186,6 +203,8 @@ class BatchedRanEnv:
                                                 _ptr(self.obs_intra), _ptr(self.reward), self._stream()),
                         "ranenv_reset")
         self._keep["last_inputs"] = (m, se)
+        if self._recorder is not None:
+            self._recorder.on_reset()
         return self._obs()
 
     def step(self, inter_scores=None, intra_choice=None, traffic_bits=None, se_tiles=None):
@@ -196,6 +215,8 @@ class BatchedRanEnv:
                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
             if st != 0:
                 self._check(st, "ranenv_step")
+            if self._recorder is not None:
+                self._recorder.on_step(None, None, self.done)
             return self._obs(), self.reward, self.done
         sc = self._dev(inter_scores, torch.float64, (self.B, self.S), "inter_scores")
         ic = self._dev(intra_choice, torch.uint8, (self.B, self.S), "intra_choice")
@@ -206,6 +227,8 @@ class BatchedRanEnv:
                                                _ptr(self.obs_intra), _ptr(self.reward), _ptr(self.done),
                                                self._stream()), "ranenv_step")
         self._keep["last_inputs"] = (sc, ic, tr, se)
+        if self._recorder is not None:
+            self._recorder.on_step(se, ic, self.done)
         return self._obs(), self.reward, self.done
 
     def step_dense(self, sched_decision, traffic_bits=None, se_tiles=None):

@@ -120,11 +120,13 @@ class MARLCommEnv:
     def _raw_obs(self, se, mobility, sched_decision):
         ce = self.comm_env
         m = {k: v[0].cpu().numpy() for k, v in self._dev.raw_observation().items()}
+        self._last_se32 = np.asarray(se)[0].astype(np.float32)       # the (U, R) tile the device consumed (tests)
         m.update({
             "mobility": mobility, "spectral_efficiencies": np.asarray(se, dtype=np.float64),
             "basestation_ue_assoc": ce.basestation_ue_assoc, "basestation_slice_assoc": ce.basestation_slice_assoc,
             "slice_ue_assoc": ce.slice_ue_assoc, "sched_decision": sched_decision, "slice_req": ce.slice_req,
         })
+        self._last_raw = m
         return m
 
     # ------------------------------------------------------------------------------------------
@@ -198,12 +200,9 @@ class MARLCommEnv:
 
     def save_history(self):
         """hist/{scenario}/{agent}/ep_{n}.npz with the 16 keys of results/gen_results.py:88-108."""
+        from .history import hist_path, write_episode_npz
         ce = self.comm_env
-        path = os.path.join(ce.root_path, "hist", ce.simu_name, ce.agent_name)
-        os.makedirs(path, exist_ok=True)
-        np.savez_compressed(os.path.join(path, f"ep_{ce.episode_number}.npz"),
-                            **{k: np.array(v, dtype=object if k in ("slice_req", "obs", "reward", "agent_action") else None)
-                               for k, v in self.hist.items()})
+        return write_episode_npz(hist_path(ce.root_path, ce.simu_name, ce.agent_name, ce.episode_number), self.hist)
 
     def close(self):
         self._dev.close()

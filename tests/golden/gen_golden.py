@@ -637,8 +637,77 @@ def plumbing_tables():
     return t
 
 
+def gen_plugins():
+    """plugins.npz: the small scenario plugins (associations/simple_slice.py, mult_slice_seq.py, simple.py,
+    channels/quadriga.py + quadriga_seq.py episode choice, channels/fixed_se.py, traffics/simple.py,
+    mobilities/simple.py), run as the reference's own classes.  ``h5py`` is absent here: a module of that
+    name with no content is enough for channels/quadriga*.py to import (only their choose_episode is called)."""
+    if "h5py" not in sys.modules:
+        try:
+            import h5py  # noqa: F401
+        except Exception:
+            sys.modules["h5py"] = types.ModuleType("h5py")
+    from associations.mult_slice_seq import MultSliceAssociationSeq
+    from associations.simple import SimpleAssociation
+    from associations.simple_slice import SimpleSliceAssociation
+    from channels.fixed_se import FixedSE
+    from channels.quadriga import QuadrigaChannel
+    from channels.quadriga_seq import QuadrigaChannelSeq
+    from mobilities.simple import SimpleMobility
+    from traffics.simple import SimpleTraffic
+    out = {}
+    rng = np.random.default_rng(10)
+    U, S, R = 4, 2, 25
+    ues = sixg.UEs(U, np.repeat(100, U), np.repeat(1024, U), np.repeat(100, U))
+
+    def req_json(req):
+        def conv(o):
+            if isinstance(o, dict):
+                return {k: conv(v) for k, v in o.items()}
+            if callable(o):
+                return "ufunc:" + o.__name__
+            if isinstance(o, (np.integer,)):
+                return int(o)
+            if isinstance(o, (np.floating,)):
+                return float(o)
+            return o
+        return json.dumps(conv(req), sort_keys=True)
+
+    ssa = SimpleSliceAssociation(ues, U, 1, S, rng, "")
+    bua = np.ones((1, U)); bsa = np.ones((1, S)); sua = np.zeros((S, U)); sua[0, :2] = 1; sua[1, 2:] = 1
+    r0 = ssa.step(bua, bsa, sua, {"old": 1}, 0, 0)
+    r5 = ssa.step(bua, bsa, sua, {"kept": 1}, 5, 0)
+    out["simple_slice_req_step0"] = np.array(req_json(r0[3]))
+    out["simple_slice_req_step5"] = np.array(req_json(r5[3]))
+    out["simple_slice_passthrough"] = np.array([int(r0[0] is bua and r0[1] is bsa and r0[2] is sua)])
+    sa = SimpleAssociation(ues, U, 1, S, rng, "")
+    rs = sa.step(bua, bsa, sua, {"x": 2}, 3, 1)
+    out["simple_passthrough"] = np.array([int(rs[0] is bua and rs[1] is bsa and rs[2] is sua and rs[3] == {"x": 2})])
+    pairs = [(e, c) for e in (0, 1, 99, 100, 101, 199, 200, 950, 1999) for c in (-1, 0, 1, 9, e // 100, e % 200)]
+    seq = MultSliceAssociationSeq(ues, U, 1, S, rng, ".")
+    ms = MultSliceAssociation(ues, U, 1, S, rng, ".")
+    qc = QuadrigaChannel(U, 1, np.array([R]), rng, ".", "x")
+    qs = QuadrigaChannelSeq(U, 1, np.array([R]), rng, ".", "x")
+    out["choose_pairs"] = np.array(pairs)
+    out["choose_mult_slice_seq"] = np.array([[int(v) for v in seq.choose_episode(e, c)] for e, c in pairs])
+    out["choose_mult_slice"] = np.array([[int(v) for v in ms.choose_episode(e, c)] for e, c in pairs])
+    out["choose_quadriga"] = np.array([[int(v) for v in qc.choose_episode(e, c)] for e, c in pairs])
+    out["choose_quadriga_seq"] = np.array([[int(v) for v in qs.choose_episode(e, c)] for e, c in pairs])
+    out["seq_attrs"] = np.array(json.dumps({"scenario_name": seq.scenario_name, "channels_per_scenario": seq.channels_per_scenario,
+                                            "generator_mode": bool(seq.generator_mode),
+                                            "channel_eps_per_scenario": qs.channel_eps_per_scenario}))
+    fse = FixedSE(U, 1, np.array([R]), rng, "", "")
+    out["fixed_se"] = np.asarray(fse.step(3, 1, np.ones((U, 2)), None))
+    out["simple_traffic"] = np.asarray(SimpleTraffic(U, rng, "").step(sua, {}, 2, 0))
+    out["simple_mobility"] = np.asarray(SimpleMobility(U, rng, "").step(2, 0))
+    out["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "plugins.npz"), **out)
+    print("plugins.npz", sorted(out))
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
+    gen_plugins()
     gen_functions()
     gen_assoc_traffic()
     ref5 = ref_tables(6, seed=10)
@@ -671,5 +740,7 @@ def gen_heads():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "heads":
         gen_heads()          # only the SchedTWC / SchedColORAN fixtures
+    elif len(sys.argv) > 1 and sys.argv[1] == "plugins":
+        gen_plugins()        # only the small scenario plugins
     else:
         main()

@@ -1,0 +1,115 @@
+"""BASELINE.json configs[1] (B 1024, MARR + round-robin) and configs[4] (mult_slice_seq sweep, B 8192, mixed
+active-slice masks) as the workloads bench.py runs: a sample of their envs against the CPU oracle at oracle-sized
+step counts, and the full batch through size-independent properties (RB and packet conservation, bounds)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL, REW_TOL = 1e-5, 1e-9
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _follow_oracle(wl, sample, steps):
+    """Step the whole workload `steps` TTIs; the envs in `sample` are mirrored by the oracle every TTI."""
+    from oracle import pyoracle
+    env = wl.env
+    S, U, R, G, Us = env.S, env.U, env.R, env.G, env.Us
+    cfg = pyoracle.make_cfg(S, U, R, G, Us, bandwidth_hz=env.bandwidth_hz, max_age_cap=env.max_age_cap, max_steps=env.max_steps)
+    se_host = wl.se_pool.transpose(1, 2).contiguous().cpu().numpy()          # oracle layout: [tile][U][R]
+    trf_host = wl.traffic_pool.cpu().numpy().astype(np.float64)
+    eps, L = env.episodes, wl.trace_len
+    intra = np.full(S, wl.intra, dtype=np.int32)
+    oenvs = {}
+    for b in sample:
+        o = pyoracle.OracleEnv(cfg)
+        o.set_scenario(wl.tables, int(wl.scenario[b]))
+        o.reset(se_host[int(eps["se_base"][b] + eps["se_offset"][b] % L)])
+        oenvs[b] = o
+    env.reset()
+    for t in range(steps):
+        obs, rew, done = env.step()
+        g = {k: x.cpu().numpy() for k, x in env.views().items()}
+        oi, oa, rw = obs["obs_inter"].cpu().numpy(), obs["obs_intra"].cpu().numpy(), rew.cpu().numpy()
+        for b, o in oenvs.items():
+            tile = int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)
+            row = int(eps["trf_base"][b] + (eps["trf_offset"][b] + t) % L)
+            sc = o.policy_mapf() if wl.policy == 2 else o.policy_marr()
+            np.testing.assert_allclose(g["policy_scores"][b], sc, rtol=0, atol=1e-12)
+            _, count, _ = o.action_format(sc, intra, want_dense=False)
+            assert np.array_equal(g["rb_count"][b], count), (t, b)
+            o.step(sc, intra, se_host[tile], trf_host[row])
+            raw, oo = o.raw(), o.obs()
+            for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (t, b, name)
+            np.testing.assert_allclose(oi[b], oo["obs_inter"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(oa[b], oo["obs_intra"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(rw[b], oo["reward"], rtol=0, atol=REW_TOL)
+    return oenvs
+
+
+def _conservation(wl, steps):
+    env, dev = wl.env, wl.env.device
+    env.reset()
+    v = env.views()
+    scen = torch.as_tensor(wl.scenario, device=dev)
+    active_any = torch.as_tensor(wl.tables.slice_active.sum(axis=1) > 0, device=dev)[scen]
+    max_pkts = torch.as_tensor(wl.tables.ue_max_pkts, device=dev)[scen].to(torch.int64)
+    ue_slice = torch.as_tensor(wl.tables.ue_slice, device=dev)[scen]
+    prev_q = v["queue_pkts"].clone().to(torch.int64)
+    for t in range(steps):
+        obs, rew, done = env.step()
+        cnt = v["rb_count"].to(torch.int64)
+        assert torch.all(cnt.sum(dim=1)[active_any] == env.R)                     # agents/ib_sched.py:345-347
+        assert torch.all(cnt[ue_slice < 0] == 0)
+        q = v["queue_pkts"].to(torch.int64)
+        inc, sent, drop = (v[k].to(torch.int64) for k in ("pkt_incoming", "pkt_effective_thr", "dropped_pkts"))
+        assert torch.all(q == prev_q + inc - drop - sent)
+        assert torch.all((q >= 0) & (q <= max_pkts)) and torch.all(sent <= v["pkt_throughputs"].to(torch.int64))
+        assert torch.isfinite(rew).all() and torch.isfinite(obs["obs_inter"]).all() and torch.isfinite(obs["obs_intra"]).all()
+        prev_q = q
+
+
+def test_config4_seq_sweep_vs_oracle():
+    """mult_slice_seq: 10 scenario groups of consecutive episodes; every env of a group replays the group's
+    association but its own channel trace (associations/mult_slice_seq.py:38-46, channels/quadriga_seq.py:28-39)."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_seq_workload
+    wl = make_mult_slice_seq_workload(40, torch.device("cuda", 0), channels_per_scenario=4, n_traces=40, trace_len=12,
+                                      max_steps=30)
+    assert wl.scenario.tolist() == [e // 4 for e in range(40)]
+    assert len(set(wl.se_trace.tolist())) == 40                               # no two envs share a channel trace
+    act = wl.tables.slice_active.sum(axis=1)
+    assert act.min() >= 3 and act.max() <= 10 and len(set(act.tolist())) > 2  # mixed masks
+    nmet = {tuple(sorted(wl.tables.param_metric[i, s, :wl.tables.slice_nparams[i, s]].tolist()))
+            for i in range(10) for s in range(10) if wl.tables.slice_has_req[i, s]}
+    assert len(nmet) >= 4                                                     # different intent metric sets: the branchy path
+    _follow_oracle(wl, list(range(40)), 30)
+    wl.env.close()
+
+
+def test_config4_full_batch_properties():
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(4, torch.device("cuda", 0), n_traces=40, trace_len=30)
+    assert wl.env.B == 8192 and "mult_slice_seq" in label
+    groups = wl.scenario.reshape(-1, 100)
+    assert np.all(groups == groups[:, :1]) and len(set(wl.scenario.tolist())) == 10
+    _conservation(wl, 20)
+    wl.env.close()
+
+
+def test_config1_marr_rr_vs_oracle_and_properties():
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(1, torch.device("cuda", 0), n_traces=20, trace_len=16)
+    assert wl.env.B == 1024 and "round-robin" in label
+    _follow_oracle(wl, list(range(0, 1024, 64)), 24)
+    _conservation(wl, 20)
+    wl.env.close()
