@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 2
+#define RANENV_ABI_VERSION 3
 
 enum {
     RANENV_OK = 0,
@@ -151,6 +151,9 @@ typedef struct {
     int8_t  *mask_inter;        /* [B][S]     player_0 action_mask                         */
     int8_t  *mask_intra;        /* [B][S][Us] player_{s+1} action_mask                     */
     double  *policy_scores;     /* [B][S] inter-slice scores used by the last step         */
+    int32_t *episode_number;    /* [B]    episode an env is playing (auto-reset; traffic generator key) */
+    int32_t *episodes;          /* [B][10] the ranenv_episode descriptors as they are on the device, viewed as
+                                   int32 words (word 0 = scenario): auto-reset rewrites them without the host   */
 } ranenv_views;
 
 const char *ranenv_last_error(ranenv_handle h);
@@ -209,6 +212,42 @@ int ranenv_profile_begin(ranenv_handle h);
 int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps);
 
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
+
+/* Offered traffic drawn on the device instead of replayed from the traffic pool: for every UE of a slice with
+ * a request, Poisson(slice Mbps) * 1e6 bits per TTI -- the law of MultSliceTraffic.step, traffics/mult_slice.py:24-32
+ * -- from a counter-based generator (Philox-4x32-10) keyed by `seed` with counter (env_id_base + env, episode
+ * number, step, UE): a function of those alone, never of the actions (the reference checks that exogenous inputs
+ * are identical across agents, results/gen_results.py:1587-1635).  Statistically, not bit-wise, equal to numpy's
+ * Generator.poisson stream; an explicit dev_traffic_bits argument of a step still takes precedence.
+ * Slice traffic must lie in (0, 128] Mbps (256-entry inversion tables, rebuilt whenever scenarios are loaded). */
+int ranenv_set_traffic_generator(ranenv_handle h, int32_t enable, uint64_t seed, int32_t env_id_base, void *stream);
+/* Diagnostic: copy the generator's inversion tables to the host: cdf [n_scenarios][S][256] uint64
+ * (floor(P(X <= k) * 2^64)), guide [n_scenarios][S][64] uint8.  A draw is the smallest k with u < cdf[k], where
+ * u = (out[1] << 32 | out[0]) of Philox-4x32-10(counter = (env id, episode, step, UE), key = (seed lo, seed hi)). */
+int ranenv_get_poisson_tables(ranenv_handle h, uint64_t *host_cdf, uint8_t *host_guide);
+
+/* Per-env episode length (host array [B]; NULL = cfg.max_steps for all): done = step_number >= max_steps[b]. */
+int ranenv_set_max_steps(ranenv_handle h, const int32_t *host_max_steps, void *stream);
+
+/* Episode advance on the device (env.reset() after `terminated`, simu.py:547-566, without the host in the loop).
+ *   ranenv_set_episode_table  descriptor of every episode number in [first_episode, first_episode + n): what
+ *                             choose_episode of the association / channel plugins resolves per episode
+ *                             (associations/mult_slice.py:444-452, mult_slice_seq.py:38-46, channels/quadriga.py:78-87,
+ *                             quadriga_seq.py:28-39)
+ *   ranenv_set_autoreset      the rule: next episode = current + 1 (wrapping from max_episode back to
+ *                             initial_episode), or uniform in [initial_episode, max_episode) when random_episodes
+ *                             (enable_random_episodes, simu.py:361,377); host_episode_no [B] = the episode every env is
+ *                             playing now (NULL keeps the device's numbers)
+ *   ranenv_autoreset          enqueue after a step: every env with dev_done != 0 gets its terminal observation
+ *                             copied to the term_* buffers (each may be NULL), the next episode's descriptor
+ *                             installed and CommunicationEnv.reset applied (obs_* receive the new episode's first
+ *                             observation; the step's rewards and done flags are left as they are).  No host sync. */
+int ranenv_set_episode_table(ranenv_handle h, const ranenv_episode *host_table, int32_t first_episode,
+                             int32_t n_episodes, void *stream);
+int ranenv_set_autoreset(ranenv_handle h, int32_t enable, int32_t initial_episode, int32_t max_episode,
+                         int32_t random_episodes, uint64_t seed, const int32_t *host_episode_no, void *stream);
+int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *dev_obs_inter, float *dev_obs_intra,
+                     float *dev_term_obs_inter, float *dev_term_obs_intra, float *dev_term_obs_head, void *stream);
 
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranenv_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
 INTRA_RR, INTRA_PF, INTRA_MT, INTRA_PER_SLICE = 0, 1, 2, 255
 F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK = 0x1, 0x2, 0x4
@@ -22,6 +22,8 @@ EXPORTS = (
     "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_profile_begin", "ranenv_profile_end",
     "ranenv_get_views",
     "ranenv_launch_info", "ranenv_se_from_power", "ranenv_bind_head_outputs", "ranenv_set_slice_usecase",
+    "ranenv_set_traffic_generator", "ranenv_set_max_steps", "ranenv_set_episode_table", "ranenv_set_autoreset",
+    "ranenv_autoreset", "ranenv_get_poisson_tables",
 )
 
 
@@ -65,6 +67,7 @@ VIEW_FIELDS = (
     ("rb_start", "i4", "BU"), ("rb_count", "i4", "BU"), ("se_mean", "f8", "BU"), ("win_sent", "i8", "BU"),
     ("win_dropped", "i8", "BU"), ("step_number", "i4", "B"), ("hist_len", "i4", "B"),
     ("mask_inter", "i1", "BS"), ("mask_intra", "i1", "BSK"), ("policy_scores", "f8", "BS"),
+    ("episode_number", "i4", "B"), ("episodes", "i4", "BE"),
 )
 
 
@@ -110,6 +113,12 @@ def load() -> C.CDLL:
     lib.ranenv_se_from_power.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]
     lib.ranenv_bind_head_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ranenv_set_slice_usecase.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.ranenv_set_traffic_generator.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_void_p]
+    lib.ranenv_get_poisson_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ranenv_set_max_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ranenv_set_episode_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.ranenv_set_autoreset.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.ranenv_autoreset.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     if lib.ranenv_abi_version() != ABI_VERSION:
         raise RanEnvError(f"ABI mismatch: library {lib.ranenv_abi_version()} != binding {ABI_VERSION}")
     _lib = lib

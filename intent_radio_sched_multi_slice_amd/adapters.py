@@ -68,6 +68,12 @@ class HeadVecEnv(_VecEnvBase):
         self._actions: Optional[torch.Tensor] = None
 
     # -- VecEnv protocol ------------------------------------------------------------------------
+    def enable_device_autoreset(self, initial_episode: int, max_episode: int, random_episodes: bool = False, seed: int = 0,
+                                episode_numbers=None):
+        """Finished envs move to their next episode and are reset on the device (BatchedRanEnv.enable_autoreset;
+        the env needs an episode table): ``step_wait`` then costs one device-to-host copy per step."""
+        self.env.enable_autoreset(initial_episode, max_episode, random_episodes, seed, episode_numbers)
+
     def reset(self):
         self.env.reset()
         return self.env.head_obs.cpu().numpy()
@@ -81,18 +87,32 @@ class HeadVecEnv(_VecEnvBase):
     def step_wait(self):
         if self._actions is None:
             raise RuntimeError("step_async was not called")
-        _, _, done = self.env.step(self._actions, self._intra)
+        env = self.env
+        _, _, done = env.step(self._actions, self._intra)
         self._actions = None
-        obs = self.env.head_obs.cpu().numpy()
-        rew = self.env.head_reward[:, self._col].cpu().numpy().astype(np.float32)
-        dones = done.cpu().numpy().astype(bool)
         infos: List[Dict] = [{} for _ in range(self.num_envs)]
-        if dones.any():                                         # auto-reset, as DummyVecEnv does
+        if env._autoreset:
+            # one packed D2H: [observation (already the next episode's first one where done) | reward | done]
+            n = env.head_obs.shape[1]
+            packed = torch.cat([env.head_obs.to(torch.float64), env.head_reward[:, self._col:self._col + 1],
+                                done.to(torch.float64)[:, None]], dim=1).cpu().numpy()
+            obs, rew, dones = packed[:, :n].astype(np.float32), packed[:, n].astype(np.float32), packed[:, n + 1] != 0
+            if dones.any():                                     # rare (once per episode and env): fetch the terminal rows
+                idx = np.nonzero(dones)[0]
+                term = env.term_head_obs[torch.as_tensor(idx, device=env.device)].cpu().numpy()
+                for j, i in enumerate(idx):
+                    infos[i]["terminal_observation"] = term[j]
+                    infos[i]["TimeLimit.truncated"] = False
+            return obs, rew, dones, infos
+        obs = env.head_obs.cpu().numpy()
+        rew = env.head_reward[:, self._col].cpu().numpy().astype(np.float32)
+        dones = done.cpu().numpy().astype(bool)
+        if dones.any():                                         # auto-reset from the host, as DummyVecEnv does
             for i in np.nonzero(dones)[0]:
                 infos[i]["terminal_observation"] = obs[i].copy()
                 infos[i]["TimeLimit.truncated"] = False
-            self.env.reset(env_mask=dones.astype(np.uint8))
-            obs[dones] = self.env.head_obs.cpu().numpy()[dones]
+            env.reset(env_mask=dones.astype(np.uint8))
+            obs[dones] = env.head_obs.cpu().numpy()[dones]
         return obs, rew, dones, infos
 
     def step(self, actions):
@@ -134,3 +154,67 @@ def marl_reward_dict(env: BatchedRanEnv, b: int) -> Dict[str, float]:
     """Env ``b``'s last rewards as calculate_reward_no_mask returns them (agents/common.py:381-439)."""
     r = env.reward[b].cpu().numpy()
     return {f"player_{i}": float(r[i]) for i in range(env.S + 1)}
+
+
+# --------------------------------------------------------------------------------------------
+# the whole batch in the reference's RLlib layout, on the device
+# --------------------------------------------------------------------------------------------
+def sorted_action_mask(action_mask: torch.Tensor) -> torch.Tensor:
+    """TorchActionMaskModel.forward's mask (agents/action_mask_model.py:46-50): the inter-slice observation lists the
+    slices sorted by requested traffic, inactive ones first, so the mask handed to the action distribution has its
+    last ``n_active`` entries set.  Batched: every row uses its own count (the reference takes row 0's for all)."""
+    n = action_mask.to(torch.int64).sum(dim=-1, keepdim=True)
+    S = action_mask.shape[-1]
+    pos = torch.arange(S, device=action_mask.device).expand_as(action_mask)
+    return (pos >= S - n).to(action_mask.dtype)
+
+
+def masked_gaussian_params(mean: torch.Tensor, log_std: torch.Tensor, masks: torch.Tensor):
+    """The inter-slice action distribution's parameters (agents/masked_action_distribution.py:30-36): std = exp(log_std);
+    where the mask is 0 the mean is -1 and the std 1e-9, so an inactive slice always gets the score -1."""
+    std = torch.exp(log_std)
+    std = torch.where(masks == 0, torch.full_like(std, 1e-9), std)
+    mean = torch.where(masks == 0, torch.full_like(mean, -1.0), mean)
+    return mean, std
+
+
+class MarlBatchEnv:
+    """B environments in the multi-agent layout the reference trains RLlib policies on, as device tensors.
+
+    Observation (IBSched.obs_space_format, agents/ib_sched.py:160-200; spaces :413-470):
+        ``obs["player_0"]``     = {"observations": float32 [B, 10*S], "action_mask": int8 [B, S]}
+        ``obs["player_{s+1}"]`` = {"observations": float32 [B, 2*Us+9], "action_mask": int8 [B, Us]}
+    Action (IBSched.get_action_space :394-411): ``{"player_0": [B, S] scores in [-1, 1] (the masked diagonal Gaussian
+    over S of masked_action_distribution.py), "player_{s+1}": [B] integers in {0, 1, 2} (Discrete(3): RR / PF / MT)}``.
+    Reward: ``{"player_i": float64 [B]}``; terminated: ``{"player_i": bool [B], "__all__": bool [B]}`` (simu.py:559-564).
+    All tensors are views of the env's buffers (zero copy); nothing here synchronises with the host.
+    """
+
+    def __init__(self, env: BatchedRanEnv):
+        self.env = env
+        env.set_policy(POLICY_EXTERNAL, 255)           # scores and schedulers come with every action
+        self.players = [f"player_{i}" for i in range(env.S + 1)]
+        self._intra = torch.zeros((env.B, env.S), dtype=torch.uint8, device=env.device)
+
+    def _obs(self):
+        env, v = self.env, self.env.views()
+        out = {"player_0": {"observations": env.obs_inter, "action_mask": v["mask_inter"]}}
+        for s in range(env.S):
+            out[f"player_{s + 1}"] = {"observations": env.obs_intra[:, s], "action_mask": v["mask_intra"][:, s]}
+        return out
+
+    def reset(self):
+        self.env.reset()
+        return self._obs(), {}
+
+    def step(self, action: Dict[str, torch.Tensor]):
+        env = self.env
+        scores = action["player_0"].to(device=env.device, dtype=torch.float64)
+        self._intra.copy_(torch.stack([action[f"player_{s + 1}"].to(env.device) for s in range(env.S)], dim=1))
+        _, reward, done = env.step(scores, self._intra)
+        rew = {p: reward[:, i] for i, p in enumerate(self.players)}
+        d = done != 0
+        term = {p: d for p in self.players}
+        term["__all__"] = d
+        trunc = {p: torch.zeros_like(d) for p in term}
+        return self._obs(), rew, term, trunc, {}

@@ -91,6 +91,8 @@ class BatchedRanEnv:
         self._step_fn = self._lib.ranenv_step
         self.policy, self.fixed_intra = POLICY_MARR, INTRA_RR      # the library's defaults (ranenv_create)
         self._recorder = None
+        self._autoreset = False
+        self.term_obs_inter = self.term_obs_intra = self.term_head_obs = None
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -160,13 +162,7 @@ class BatchedRanEnv:
 
     def set_episodes(self, scenario, se_base=0, se_len=1, se_offset=0, trf_base=0, trf_len=1, trf_offset=0):
         """Which scenario / channel trace / traffic trace each env replays (arrays of [B] or scalars)."""
-        eps = np.zeros(self.B, dtype=[("scenario", "<i4"), ("se_len", "<i4"), ("se_base", "<i8"),
-                                      ("se_offset", "<i4"), ("trf_len", "<i4"), ("trf_base", "<i8"),
-                                      ("trf_offset", "<i4"), ("reserved", "<i4")])
-        assert eps.dtype.itemsize == C.sizeof(_lib.Episode)
-        for k, v in (("scenario", scenario), ("se_len", se_len), ("se_base", se_base), ("se_offset", se_offset),
-                     ("trf_len", trf_len), ("trf_base", trf_base), ("trf_offset", trf_offset)):
-            eps[k] = np.broadcast_to(np.asarray(v), (self.B,))
+        eps = self._episode_array(self.B, scenario, se_base, se_len, se_offset, trf_base, trf_len, trf_offset)
         with torch.cuda.device(self.device):
             self._check(self._lib.ranenv_set_episodes(self._h, C.c_void_p(eps.ctypes.data), self._stream()),
                         "ranenv_set_episodes")
@@ -175,6 +171,102 @@ class BatchedRanEnv:
     def set_policy(self, policy: int = POLICY_EXTERNAL, fixed_intra: int = INTRA_PER_SLICE):
         self._check(self._lib.ranenv_set_policy(self._h, int(policy), int(fixed_intra)), "ranenv_set_policy")
         self.policy, self.fixed_intra = int(policy), int(fixed_intra)
+
+    _EP_DTYPE = [("scenario", "<i4"), ("se_len", "<i4"), ("se_base", "<i8"), ("se_offset", "<i4"), ("trf_len", "<i4"),
+                 ("trf_base", "<i8"), ("trf_offset", "<i4"), ("reserved", "<i4")]
+
+    def _episode_array(self, n, scenario, se_base, se_len, se_offset, trf_base, trf_len, trf_offset):
+        eps = np.zeros(n, dtype=self._EP_DTYPE)
+        assert eps.dtype.itemsize == C.sizeof(_lib.Episode)
+        for k, v in (("scenario", scenario), ("se_len", se_len), ("se_base", se_base), ("se_offset", se_offset),
+                     ("trf_len", trf_len), ("trf_base", trf_base), ("trf_offset", trf_offset)):
+            eps[k] = np.broadcast_to(np.asarray(v), (n,))
+        return eps
+
+    def episode_descriptors(self) -> np.ndarray:
+        """The per-env episode descriptors as they are on the device now (structured array; one small D2H)."""
+        if not self._autoreset:
+            return self.episodes
+        raw = self.views()["episodes"].cpu().numpy()
+        return np.ascontiguousarray(raw).view(self._EP_DTYPE).reshape(self.B)
+
+    def set_traffic_generator(self, seed: int, env_id_base: int = 0, enable: bool = True):
+        """Draw the offered traffic on the device -- Poisson(slice Mbps) * 1e6 bits per UE and TTI
+        (traffics/mult_slice.py:24-32), Philox-4x32-10 keyed (seed; env_id_base + env, episode, step, UE) --
+        instead of replaying the traffic pool."""
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_traffic_generator(self._h, 1 if enable else 0, int(seed) & (2 ** 64 - 1),
+                                                               int(env_id_base), self._stream()), "ranenv_set_traffic_generator")
+        self.traffic_seed, self.env_id_base = (int(seed) & (2 ** 64 - 1), int(env_id_base)) if enable else (None, 0)
+
+    def poisson_tables(self):
+        """Diagnostic: the traffic generator's inversion tables -> (cdf uint64 [NS, S, 256], guide uint8 [NS, S, 64])."""
+        cdf = np.zeros((self.n_scenarios, self.S, 256), dtype=np.uint64)
+        guide = np.zeros((self.n_scenarios, self.S, 64), dtype=np.uint8)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_get_poisson_tables(self._h, C.c_void_p(cdf.ctypes.data), C.c_void_p(guide.ctypes.data)),
+                        "ranenv_get_poisson_tables")
+        return cdf, guide
+
+    def set_max_steps(self, max_steps=None):
+        """Per-env episode length ([B] ints) or None for the constructor's max_steps everywhere."""
+        if max_steps is None:
+            self._check(self._lib.ranenv_set_max_steps(self._h, None, self._stream()), "ranenv_set_max_steps")
+            return
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(max_steps, dtype=np.int32), (self.B,)))
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_max_steps(self._h, C.c_void_p(a.ctypes.data), self._stream()), "ranenv_set_max_steps")
+
+    def set_episode_table(self, scenario, se_base=0, se_len=1, se_offset=0, trf_base=0, trf_len=1, trf_offset=0,
+                          first_episode: int = 0):
+        """Descriptor of every episode number in [first_episode, first_episode + len(scenario)): what the plugins'
+        choose_episode resolves per episode (associations/mult_slice.py:444-452, channels/quadriga.py:78-87)."""
+        n = len(np.atleast_1d(scenario))
+        tab = self._episode_array(n, scenario, se_base, se_len, se_offset, trf_base, trf_len, trf_offset)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_episode_table(self._h, C.c_void_p(tab.ctypes.data), int(first_episode), n,
+                                                           self._stream()), "ranenv_set_episode_table")
+        self.episode_table, self.episode_table_first = tab, int(first_episode)
+
+    def enable_autoreset(self, initial_episode: int, max_episode: int, random_episodes: bool = False, seed: int = 0,
+                         episode_numbers=None):
+        """After every step, envs that reported ``done`` move to their next episode on the device (sequential, or
+        random in [initial, max) like enable_random_episodes, simu.py:361,377) and are reset, without a host sync.
+        ``episode_numbers`` [B]: the episode every env plays now (its descriptor is installed here).  The terminal
+        observation of those envs is kept in ``term_obs_inter`` / ``term_obs_intra`` (/ ``term_head_obs``)."""
+        ep = None
+        if episode_numbers is not None:
+            ep = np.ascontiguousarray(np.broadcast_to(np.asarray(episode_numbers, dtype=np.int32), (self.B,)))
+            rows = ep - self.episode_table_first
+            if rows.min() < 0 or rows.max() >= len(self.episode_table):
+                raise RanEnvError("episode_numbers outside the episode table")
+            t = self.episode_table[rows]
+            self.set_episodes(scenario=t["scenario"], se_base=t["se_base"], se_len=t["se_len"], se_offset=t["se_offset"],
+                              trf_base=t["trf_base"], trf_len=t["trf_len"], trf_offset=t["trf_offset"])
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_autoreset(self._h, 1, int(initial_episode), int(max_episode),
+                                                       1 if random_episodes else 0, int(seed) & (2 ** 64 - 1),
+                                                       None if ep is None else C.c_void_p(ep.ctypes.data), self._stream()),
+                        "ranenv_set_autoreset")
+        self.term_obs_inter = torch.zeros_like(self.obs_inter)
+        self.term_obs_intra = torch.zeros_like(self.obs_intra)
+        if getattr(self, "head_obs", None) is not None:
+            self.term_head_obs = torch.zeros_like(self.head_obs)
+        self._autoreset = True
+
+    def disable_autoreset(self):
+        self._check(self._lib.ranenv_set_autoreset(self._h, 0, 0, 0, 0, 0, None, self._stream()), "ranenv_set_autoreset")
+        self._autoreset = False
+
+    def _after_step(self, se, ic):
+        if self._recorder is not None:
+            self._recorder.on_step(se, ic, self.done)
+        if self._autoreset:
+            st = self._lib.ranenv_autoreset(self._h, _ptr(self.done), _ptr(self.obs_inter), _ptr(self.obs_intra),
+                                            _ptr(self.term_obs_inter), _ptr(self.term_obs_intra), _ptr(self.term_head_obs),
+                                            self._stream())
+            if st != 0:
+                self._check(st, "ranenv_autoreset")
 
     def record(self, envs, root_path: str = ".", simu_name: str = "mult_slice", agent_name: str = "agent",
                episode_numbers=None, marl: bool = True):
@@ -215,8 +307,8 @@ class BatchedRanEnv:
                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
             if st != 0:
                 self._check(st, "ranenv_step")
-            if self._recorder is not None:
-                self._recorder.on_step(None, None, self.done)
+            if self._recorder is not None or self._autoreset:
+                self._after_step(None, None)
             return self._obs(), self.reward, self.done
         sc = self._dev(inter_scores, torch.float64, (self.B, self.S), "inter_scores")
         ic = self._dev(intra_choice, torch.uint8, (self.B, self.S), "intra_choice")
@@ -227,8 +319,8 @@ class BatchedRanEnv:
                                                _ptr(self.obs_intra), _ptr(self.reward), _ptr(self.done),
                                                self._stream()), "ranenv_step")
         self._keep["last_inputs"] = (sc, ic, tr, se)
-        if self._recorder is not None:
-            self._recorder.on_step(se, ic, self.done)
+        if self._recorder is not None or self._autoreset:
+            self._after_step(se, ic)
         return self._obs(), self.reward, self.done
 
     def step_dense(self, sched_decision, traffic_bits=None, se_tiles=None):
@@ -258,6 +350,8 @@ class BatchedRanEnv:
         self.head_reward = torch.zeros((self.B, 2), dtype=torch.float64, device=self.device)
         self._check(self._lib.ranenv_bind_head_outputs(self._h, _ptr(self.head_obs), _ptr(self.head_reward)),
                     "ranenv_bind_head_outputs")
+        if self._autoreset:
+            self.term_head_obs = torch.zeros_like(self.head_obs)
         if slice_usecase is not None:
             self.set_slice_usecase(slice_usecase)
 
@@ -273,7 +367,7 @@ class BatchedRanEnv:
         if self._views is None:
             v = _lib.Views()
             self._check(self._lib.ranenv_get_views(self._h, C.byref(v)), "ranenv_get_views")
-            dims = {"B": self.B, "U": self.U, "S": self.S, "K": self.Us}
+            dims = {"B": self.B, "U": self.U, "S": self.S, "K": self.Us, "E": C.sizeof(_lib.Episode) // 4}
             out = {}
             for name, ts, shp in _lib.VIEW_FIELDS:
                 shape = tuple(dims[c] for c in shp)
@@ -288,7 +382,7 @@ class BatchedRanEnv:
         v = self.views()
         if self.tables is None or self.episodes is None:
             raise RanEnvError("raw_observation needs load_scenarios + set_episodes")
-        scen = torch.as_tensor(self.episodes["scenario"].astype(np.int64), device=self.device)
+        scen = v["episodes"][:, 0].to(torch.int64)           # as on the device: auto-reset may have moved on
         max_pkts = torch.as_tensor(self.tables.ue_max_pkts, device=self.device)[scen].to(torch.float64)
         q = v["queue_pkts"].to(torch.float64)
         lat = torch.where(q > 0, v["queue_age_sum"].to(torch.float64) / q.clamp(min=1), torch.zeros_like(q))

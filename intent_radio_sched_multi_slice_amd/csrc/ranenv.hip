@@ -74,6 +74,7 @@ struct State {
     int8_t *mask_inter, *mask_intra; double *policy_scores;
     // allocation made at the end of a step for the next one (device policy): valid while alloc_gen[e] == KP::alloc_gen
     int32_t *alloc_gen, *next_rb_start, *next_rb_count; double *next_scores;
+    int32_t *episode_no, *reset_count;      // [B] episode number an env is playing / resets it went through (auto-reset)
 };
 
 struct KP {
@@ -89,6 +90,11 @@ struct KP {
     const ranenv_episode *episodes;
     const float *se_pool; long long se_stride;
     const int32_t *trf_pool;
+    // counter-based traffic (ranenv_set_traffic_generator): Poisson draws keyed (seed; env id, episode, step, UE)
+    int trf_gen; int env_id_base; unsigned long long trf_seed;
+    const unsigned long long *pois_cdf;   // [NS][S][256] floor(P(X <= k) * 2^64), saturated
+    const uint8_t *pois_guide;            // [NS][S][64]  smallest k with cdf[k] > j * 2^58
+    const int32_t *max_steps_env;         // [B] per-env episode length or null (= max_steps)
     // per-call inputs (may be null)
     const uint8_t *env_mask;
     const double *scores; const uint8_t *intra; const double *traffic_bits; const float *se_tiles;
@@ -304,6 +310,33 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
     }
     if (pl.n_leaves == 1) { full = lf; part = lg; return; }
     full = lf + rf; part = lg + rg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based random numbers: Philox-4x32-10 (Salmon et al., SC'11).  One call = 128 random bits that depend
+// only on (key, counter): the exogenous inputs of an env never depend on what the agent did
+// (results/gen_results.py:1587-1635 checks exactly that across agents).
+// ---------------------------------------------------------------------------------------------
+DEVFN void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Poisson draw by table inversion: u = 64 random bits, result = smallest k with u < cdf[k]; the guide table
+// (indexed by the top 6 bits of u) gives a k at or below the answer, so the walk is a step or two.
+DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsigned long long u)
+{
+    int k = guide[u >> 58];
+    while (k < 255 && cdf[k] <= u) k++;
+    return k;
 }
 
 #if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of thread 0 at up to S phase boundaries of the step
@@ -604,8 +637,10 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     int old_s = 0, old_d = 0;
     if (hlen == D) { old_s = *rs; old_d = *rd; }
     double traffic = 0.0;
-    if (MODE != MODE_RESET)
+    const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
+    if (MODE != MODE_RESET && !gen_traffic)
         traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
+    const int episode_no = gen_traffic ? uni(p.st.episode_no[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
     SeStream se1;
     se1.init(tile, U, u, R);                       // lane = UE: one dword per RB
@@ -680,6 +715,20 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         if (MODE != MODE_RESET) {
             const double psz = (double)pkt_size;
             // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
+            if (gen_traffic) {
+                // MultSliceTraffic.step (traffics/mult_slice.py:24-32): Poisson(slice Mbps) * 1e6 bits for the UEs of a
+                // slice that has a request, 0 elsewhere; drawn here instead of replayed
+                traffic = 0.0;
+                if (slc >= 0 && has_req && sh.sf[slc][1] > 0.0) {
+                    unsigned rnd[4];
+                    philox4x32_10((unsigned)(p.env_id_base + e), (unsigned)episode_no, (unsigned)t, (unsigned)u,
+                                  (unsigned)p.trf_seed, (unsigned)(p.trf_seed >> 32), rnd);
+                    const size_t row = (size_t)sc * S + slc;
+                    const int k = poisson_draw(p.pois_cdf + row * 256, p.pois_guide + row * 64,
+                                               ((unsigned long long)rnd[1] << 32) | rnd[0]);
+                    traffic = (double)k * 1e6;
+                }
+            }
             pkt_thr = (int)((se_part * p.bw_per_rb) / psz);
             pkt_in = (int)(traffic / psz);
             const int L = p.L;
@@ -914,7 +963,8 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
             p.st.se_pos[e] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
             p.st.trf_pos[e] = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
         }
-        if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= p.max_steps) ? 1 : 0;
+        const int max_steps_e = p.max_steps_env ? p.max_steps_env[e] : p.max_steps;
+        if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= max_steps_e) ? 1 : 0;
     }
     } while (0);
     RANENV_STAMP(7);
@@ -1147,6 +1197,46 @@ __global__ void __launch_bounds__(256) ranenv_se_from_power_kernel(const double 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Auto-reset, part 1 (part 2 is the step kernel in RESET mode under the mask written here): one workgroup
+// per env.  For an env whose episode just ended (done != 0): keep its terminal observation, pick the next
+// episode number -- sequential from `initial`, or random in [initial, max) (simu.py:361,377,546; the draw is
+// counter-based: seed, env id, resets so far) -- and install that episode's descriptor from the table.
+// ---------------------------------------------------------------------------------------------
+struct AdvanceArgs {
+    const uint8_t *done; uint8_t *mask;
+    ranenv_episode *episodes; const ranenv_episode *table; int table_first, table_n;
+    int32_t *episode_no, *reset_count;
+    int initial, max_ep, random, env_id_base; unsigned long long seed;
+    const float *obs_inter, *obs_intra, *head_obs; float *term_inter, *term_intra, *term_head;
+    int n_inter, n_intra, n_head;
+};
+
+__global__ void __launch_bounds__(64) ranenv_advance_kernel(const AdvanceArgs a)
+{
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const bool d = a.done[e] != 0;
+    if (tid == 0) a.mask[e] = d ? 1 : 0;
+    if (!d) return;
+    if (a.term_inter) for (int i = tid; i < a.n_inter; i += 64) a.term_inter[(size_t)e * a.n_inter + i] = a.obs_inter[(size_t)e * a.n_inter + i];
+    if (a.term_intra) for (int i = tid; i < a.n_intra; i += 64) a.term_intra[(size_t)e * a.n_intra + i] = a.obs_intra[(size_t)e * a.n_intra + i];
+    if (a.term_head && a.head_obs) for (int i = tid; i < a.n_head; i += 64) a.term_head[(size_t)e * a.n_head + i] = a.head_obs[(size_t)e * a.n_head + i];
+    if (tid == 0) {
+        const int cur = a.episode_no[e], cnt = a.reset_count[e] + 1;
+        int next;
+        if (a.random) {
+            unsigned rnd[4];
+            philox4x32_10((unsigned)(a.env_id_base + e), (unsigned)cnt, 0x45504953u /* "EPIS" */, 0u,
+                          (unsigned)a.seed, (unsigned)(a.seed >> 32), rnd);
+            next = a.initial + (int)(rnd[0] % (unsigned)(a.max_ep - a.initial));
+        } else {
+            next = cur + 1 < a.max_ep ? cur + 1 : a.initial;
+        }
+        a.episode_no[e] = next; a.reset_count[e] = cnt;
+        a.episodes[e] = a.table[next - a.table_first];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
@@ -1160,6 +1250,12 @@ struct ranenv {
     ranenv_episode *d_episodes = nullptr;
     bool have_scenarios = false, have_episodes = false;
     int alloc_gen = 1;                          // bumped by everything a stored next-TTI allocation depends on
+    ranenv_episode *d_ep_table = nullptr; int ep_table_first = 0, ep_table_n = 0;     // auto-reset: episode number -> descriptor
+    int ar_initial = 0, ar_max = 0, ar_random = 0; unsigned long long ar_seed = 0; bool ar_on = false;
+    uint8_t *d_ar_mask = nullptr;
+    unsigned long long *d_pois_cdf = nullptr; uint8_t *d_pois_guide = nullptr; int32_t *d_max_steps = nullptr;
+    std::vector<double> slice_traffic;          // [NS][S] host copy (traffic generator tables)
+    std::vector<int32_t> slice_has_req;
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
@@ -1203,6 +1299,55 @@ int dev_alloc(ranenv_handle h, T **out, size_t count)
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "hipMemset: %s", hipGetErrorString(e));
     h->allocs.push_back(ptr);
     *out = (T *)ptr;
+    return RANENV_OK;
+}
+
+size_t NS_all(ranenv_handle h) { return (size_t)h->cfg.n_scenarios * (size_t)h->cfg.n_slices; }
+
+// Inversion tables of the traffic generator, one row per (scenario, slice): cdf[k] = floor(P(X <= k) * 2^64) for
+// X ~ Poisson(slice Mbps), k = 0..255 (lower half summed upwards, upper half as 1 - survival, the survival
+// function summed from the tail so that the far tail keeps its relative precision), and the 64-entry guide.
+int build_poisson_tables(ranenv_handle h, hipStream_t stream)
+{
+    const size_t rows = NS_all(h);
+    if (h->slice_traffic.size() != rows) return RANENV_OK;          // no scenarios yet: built when they are loaded
+    std::vector<unsigned long long> cdf(rows * 256, ~0ull);
+    std::vector<uint8_t> guide(rows * 64, 0);
+    const long double two64 = 18446744073709551616.0L;
+    for (size_t r = 0; r < rows; r++) {
+        const double lam = h->slice_traffic[r];
+        if (!h->slice_has_req[r] || lam == 0.0) continue;          // never sampled
+        if (!(lam > 0.0) || lam > 128.0)
+            return fail(h, RANENV_E_INVALID, "traffic generator: slice traffic %g Mbps outside (0, 128] (256-entry inversion table)", lam);
+        long double pmf[256], ll = logl((long double)lam);
+        for (int k = 0; k < 256; k++) pmf[k] = expl((long double)k * ll - (long double)lam - lgammal((long double)k + 1.0L));
+        const int mode = (int)lam;
+        unsigned long long *c = &cdf[r * 256];
+        long double cum = 0.0L;
+        for (int k = 0; k <= mode; k++) { cum += pmf[k]; const long double v = floorl(cum * two64); c[k] = v >= two64 ? ~0ull : (unsigned long long)v; }
+        long double sf = 0.0L;                                      // P(X > k), from the tail
+        for (int k = 255; k > mode; k--) {
+            const long double v = ceill(sf * two64);
+            c[k] = v <= 0.0L ? ~0ull : (v >= two64 ? 0ull : (unsigned long long)(two64 - v));
+            sf += pmf[k];
+        }
+        c[255] = ~0ull;
+        for (int k = 1; k < 256; k++) if (c[k] < c[k - 1]) c[k] = c[k - 1];      // monotone across the seam at the mode
+        uint8_t *g = &guide[r * 64];
+        int k = 0;
+        for (int j = 0; j < 64; j++) {
+            const unsigned long long lo = (unsigned long long)j << 58;
+            while (k < 255 && c[k] <= lo) k++;
+            g[j] = (uint8_t)k;
+        }
+    }
+    if (!h->d_pois_cdf) {
+        if (dev_alloc(h, &h->d_pois_cdf, rows * 256) != RANENV_OK || dev_alloc(h, &h->d_pois_guide, rows * 64) != RANENV_OK) return RANENV_E_NOMEM;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_pois_cdf, cdf.data(), cdf.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pois_guide, guide.data(), guide.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    h->kp.pois_cdf = h->d_pois_cdf; h->kp.pois_guide = h->d_pois_guide;
     return RANENV_OK;
 }
 
@@ -1310,7 +1455,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
         ALLOC(kp.tab.slice_usecase, NS * S);
     }
-    ALLOC(h->d_episodes, B);
+    ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B);
+    ALLOC(kp.st.episode_no, B); ALLOC(kp.st.reset_count, B);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
@@ -1414,6 +1560,9 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
 #undef PUT
     HIP_TRY(h, hipStreamSynchronize(stream));  // staging vectors die at return
     h->have_scenarios = true; h->alloc_gen++;
+    if (h->slice_traffic.size() != NS_all(h)) { h->slice_traffic.assign(NS_all(h), 0.0); h->slice_has_req.assign(NS_all(h), 0); }
+    for (size_t i = 0; i < n * S; i++) { h->slice_traffic[f * S + i] = t->slice_traffic[i]; h->slice_has_req[f * S + i] = t->slice_has_req[i]; }
+    if (h->kp.trf_gen) { const int rc = build_poisson_tables(h, stream); if (rc != RANENV_OK) return rc; }
     return RANENV_OK;
 }
 
@@ -1478,7 +1627,8 @@ static int check_ready(ranenv_handle h, const float *se_tiles, const double *tra
     if (!h->have_scenarios) return fail(h, RANENV_E_STATE, "no scenarios loaded (ranenv_load_scenarios)");
     if (!h->have_episodes) return fail(h, RANENV_E_STATE, "no episode descriptors (ranenv_set_episodes)");
     if (!se_tiles && !h->kp.se_pool) return fail(h, RANENV_E_STATE, "no SE tiles given and no SE pool bound");
-    if (need_traffic && !traffic_bits && !h->kp.trf_pool) return fail(h, RANENV_E_STATE, "no traffic given and no traffic pool bound");
+    if (need_traffic && !traffic_bits && !h->kp.trf_pool && !h->kp.trf_gen)
+        return fail(h, RANENV_E_STATE, "no traffic given, no traffic pool bound and no traffic generator set");
     return RANENV_OK;
 }
 
@@ -1545,6 +1695,125 @@ int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps)
     return RANENV_OK;
 }
 
+int ranenv_set_traffic_generator(ranenv_handle h, int32_t enable, uint64_t seed, int32_t env_id_base, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!enable) { h->kp.trf_gen = 0; return RANENV_OK; }
+    if (env_id_base < 0) return fail(h, RANENV_E_INVALID, "env_id_base must be >= 0");
+    h->kp.trf_seed = seed; h->kp.env_id_base = env_id_base;
+    h->kp.trf_gen = 1;
+    const int rc = build_poisson_tables(h, (hipStream_t)stream_);
+    if (rc != RANENV_OK) h->kp.trf_gen = 0;
+    return rc;
+}
+
+int ranenv_get_poisson_tables(ranenv_handle h, uint64_t *host_cdf, uint8_t *host_guide)
+{
+    if (!h || !host_cdf || !host_guide) return fail(h, RANENV_E_INVALID, "null argument");
+    if (!h->kp.trf_gen || !h->d_pois_cdf) return fail(h, RANENV_E_STATE, "the traffic generator is not enabled");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(host_cdf, h->d_pois_cdf, NS_all(h) * 256 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(host_guide, h->d_pois_guide, NS_all(h) * 64, hipMemcpyDeviceToHost));
+    return RANENV_OK;
+}
+
+int ranenv_set_max_steps(ranenv_handle h, const int32_t *host_max_steps, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!host_max_steps) { h->kp.max_steps_env = nullptr; return RANENV_OK; }
+    for (int b = 0; b < h->cfg.batch; b++) if (host_max_steps[b] < 1) return fail(h, RANENV_E_INVALID, "env %d: max_steps must be >= 1", b);
+    if (!h->d_max_steps && dev_alloc(h, &h->d_max_steps, (size_t)h->cfg.batch) != RANENV_OK) return RANENV_E_NOMEM;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(h, hipMemcpyAsync(h->d_max_steps, host_max_steps, sizeof(int32_t) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    h->kp.max_steps_env = h->d_max_steps;
+    return RANENV_OK;
+}
+
+static int check_episode(ranenv_handle h, const ranenv_episode &e, const char *what, long long idx)
+{
+    if (e.scenario < 0 || e.scenario >= h->cfg.n_scenarios) return fail(h, RANENV_E_INVALID, "%s %lld: scenario %d outside pool of %d", what, idx, e.scenario, h->cfg.n_scenarios);
+    if (e.se_len < 1 || e.se_offset < 0 || e.se_offset >= e.se_len || e.se_base < 0 || e.trf_len < 1 ||
+        e.trf_offset < 0 || e.trf_offset >= e.trf_len || e.trf_base < 0)
+        return fail(h, RANENV_E_INVALID, "%s %lld: need len >= 1, 0 <= offset < len, base >= 0", what, idx);
+    if (h->kp.se_pool && e.se_base + e.se_len > h->se_tiles_n)
+        return fail(h, RANENV_E_INVALID, "%s %lld: SE trace [%lld,+%d) exceeds the bound pool of %lld tiles", what, idx, (long long)e.se_base, e.se_len, (long long)h->se_tiles_n);
+    if (h->kp.trf_pool && e.trf_base + e.trf_len > h->trf_rows_n)
+        return fail(h, RANENV_E_INVALID, "%s %lld: traffic trace [%lld,+%d) exceeds the bound pool of %lld rows", what, idx, (long long)e.trf_base, e.trf_len, (long long)h->trf_rows_n);
+    return RANENV_OK;
+}
+
+int ranenv_set_episode_table(ranenv_handle h, const ranenv_episode *host_table, int32_t first_episode, int32_t n_episodes, void *stream_)
+{
+    if (!h || !host_table) return fail(h, RANENV_E_INVALID, "null argument");
+    if (n_episodes < 1 || first_episode < 0) return fail(h, RANENV_E_INVALID, "need n_episodes >= 1 and first_episode >= 0");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (int i = 0; i < n_episodes; i++) { const int rc = check_episode(h, host_table[i], "episode table entry", i); if (rc != RANENV_OK) return rc; }
+    ranenv_episode *d = nullptr;
+    if (dev_alloc(h, &d, (size_t)n_episodes) != RANENV_OK) return RANENV_E_NOMEM;      // (an older table stays allocated until destroy)
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(h, hipMemcpyAsync(d, host_table, sizeof(ranenv_episode) * (size_t)n_episodes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    h->d_ep_table = d; h->ep_table_first = first_episode; h->ep_table_n = n_episodes;
+    h->ar_on = false;                      // the rule is re-validated against the new table
+    return RANENV_OK;
+}
+
+int ranenv_set_autoreset(ranenv_handle h, int32_t enable, int32_t initial_episode, int32_t max_episode, int32_t random_episodes,
+                         uint64_t seed, const int32_t *host_episode_no, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (!enable) { h->ar_on = false; return RANENV_OK; }
+    if (!h->d_ep_table) return fail(h, RANENV_E_STATE, "no episode table (ranenv_set_episode_table)");
+    if (initial_episode < h->ep_table_first || max_episode <= initial_episode || max_episode > h->ep_table_first + h->ep_table_n)
+        return fail(h, RANENV_E_INVALID, "episodes [%d,%d) must be a non-empty range inside the table [%d,%d)", initial_episode, max_episode,
+                    h->ep_table_first, h->ep_table_first + h->ep_table_n);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (host_episode_no) {
+        for (int b = 0; b < h->cfg.batch; b++)
+            if (host_episode_no[b] < h->ep_table_first || host_episode_no[b] >= h->ep_table_first + h->ep_table_n)
+                return fail(h, RANENV_E_INVALID, "env %d: episode number %d outside the table", b, host_episode_no[b]);
+        HIP_TRY(h, hipMemcpyAsync(h->kp.st.episode_no, host_episode_no, sizeof(int32_t) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
+        HIP_TRY(h, hipMemsetAsync(h->kp.st.reset_count, 0, sizeof(int32_t) * (size_t)h->cfg.batch, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+    }
+    h->ar_initial = initial_episode; h->ar_max = max_episode; h->ar_random = random_episodes ? 1 : 0; h->ar_seed = seed;
+    h->ar_on = true;
+    return RANENV_OK;
+}
+
+int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter, float *obs_intra,
+                     float *term_obs_inter, float *term_obs_intra, float *term_obs_head, void *stream_)
+{
+    if (!h || !dev_done) return fail(h, RANENV_E_INVALID, "null argument");
+    if (!h->ar_on) return fail(h, RANENV_E_STATE, "auto-reset is not configured (ranenv_set_autoreset)");
+    int rc = check_ready(h, nullptr, nullptr, false);
+    if (rc != RANENV_OK) return rc;
+    if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int S = h->cfg.n_slices, Us = h->cfg.max_ues_slice;
+    AdvanceArgs a;
+    a.done = dev_done; a.mask = h->d_ar_mask; a.episodes = h->d_episodes; a.table = h->d_ep_table;
+    a.table_first = h->ep_table_first; a.table_n = h->ep_table_n;
+    a.episode_no = h->kp.st.episode_no; a.reset_count = h->kp.st.reset_count;
+    a.initial = h->ar_initial; a.max_ep = h->ar_max; a.random = h->ar_random; a.env_id_base = h->kp.env_id_base; a.seed = h->ar_seed;
+    a.obs_inter = obs_inter; a.obs_intra = obs_intra; a.head_obs = h->kp.head_obs;
+    a.term_inter = obs_inter ? term_obs_inter : nullptr; a.term_intra = obs_intra ? term_obs_intra : nullptr; a.term_head = term_obs_head;
+    a.n_inter = S * 10; a.n_intra = S * (2 * Us + 9); a.n_head = S * 10;
+    hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, a);
+    KP kp = h->kp;
+    kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
+    kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = nullptr; kp.done = nullptr;   // the step's rewards stay
+    const hipError_t e = launch<MODE_RESET>(h, kp, stream);
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "auto-reset launch: %s", hipGetErrorString(e));
+    return RANENV_OK;
+}
+
 int ranenv_get_views(ranenv_handle h, ranenv_views *out)
 {
     if (!h || !out) return fail(h, RANENV_E_INVALID, "null argument");
@@ -1556,6 +1825,8 @@ int ranenv_get_views(ranenv_handle h, ranenv_views *out)
     out->win_sent = (int64_t *)s.win_sent; out->win_dropped = (int64_t *)s.win_dropped;
     out->step_number = s.step_no; out->hist_len = s.hist_len;
     out->mask_inter = s.mask_inter; out->mask_intra = s.mask_intra; out->policy_scores = s.policy_scores;
+    out->episode_number = s.episode_no;
+    out->episodes = reinterpret_cast<int32_t *>(h->d_episodes);
     return RANENV_OK;
 }
 

@@ -77,10 +77,12 @@ class HistoryRecorder:
             "obs_inter": z(T, n, S * 10, dt=torch.float32), "obs_intra": z(T, n, S, env.W, dt=torch.float32),
         }
         self.t = 0
+        self._scen_at_start = np.array(env.episode_descriptors()["scenario"])[self.envs]
         self.written: List[str] = []
 
     def on_reset(self):
         self.t = 0
+        self._scen_at_start = np.array(self.env.episode_descriptors()["scenario"])[self.envs]
 
     def on_step(self, se_tiles, intra_choice, done):
         """Called by BatchedRanEnv.step after the launch; ``se_tiles`` = explicit tiles of this step or None (pool)."""
@@ -102,7 +104,7 @@ class HistoryRecorder:
         if se_tiles is not None:
             self.buf["se"][t] = se_tiles.index_select(0, i)
         else:
-            eps = env.episodes
+            eps = env.episode_descriptors()
             tile = eps["se_base"][self.envs] + (eps["se_offset"][self.envs] + t) % eps["se_len"][self.envs]
             self.buf["se"][t] = env._keep["se_pool"].index_select(0, torch.as_tensor(tile, device=env.device))
         self.t = t + 1
@@ -119,7 +121,7 @@ class HistoryRecorder:
         paths = []
         for k in which:
             e = self.envs[k]
-            scen = int(env.episodes["scenario"][e])
+            scen = int(self._scen_at_start[k])
             bua, bsa, sua, req = env.tables.to_reference(scen)
             max_pkts = env.tables.ue_max_pkts[scen].astype(np.float64)
             q = host["queue_pkts"][:, k].astype(np.float64)

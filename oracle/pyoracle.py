@@ -118,6 +118,44 @@ def quadriga_se_from_power(target_cell_power: np.ndarray, n_rbs: int, transmissi
     return np.log2(1 + np.divide((transmission_power / n_rbs) * g, interference + thermal_noise_power))
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), the
+    checker for the device generator: counter words c0..c3 (arrays broadcast together), key (k0, k1) -> 4 uint32
+    arrays.  Round: (c0, c1, c2, c3) <- (hi(M1*c2) ^ c1 ^ k0, lo(M1*c2), hi(M0*c0) ^ c3 ^ k1, lo(M0*c0)); key += (W0, W1)."""
+    m32 = np.uint64(0xFFFFFFFF)
+    c = [np.asarray(x, dtype=np.uint64) & m32 for x in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(k0) & m32, np.uint64(k1) & m32
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & m32, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & m32]
+        k0, k1 = (k0 + W0) & m32, (k1 + W1) & m32
+    return c
+
+
+def poisson_from_tables(cdf_row: np.ndarray, u: np.ndarray) -> np.ndarray:
+    """Inversion as the device does it: smallest k with u < cdf[k] (k capped at 255)."""
+    return np.minimum(np.searchsorted(cdf_row, u, side="right"), 255)
+
+
+def generator_traffic(cdf, tables, scenario: int, seed: int, env_id: int, episode: int, step: int) -> np.ndarray:
+    """[U] offered bits of one env and TTI as ranenv_set_traffic_generator defines them: Poisson(slice Mbps) * 1e6
+    for the UEs of slices with a request (traffics/mult_slice.py:24-32), u = (x1 << 32 | x0) of
+    Philox-4x32-10(counter (env_id, episode, step, ue), key (seed lo, seed hi))."""
+    U, S = tables.n_ues, tables.n_slices
+    out = np.zeros(U)
+    ue = np.arange(U, dtype=np.uint64)
+    x = philox4x32_10(env_id, episode, step, ue, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = (x[1] << np.uint64(32)) | x[0]
+    for s in range(S):
+        n = int(tables.slice_nues[scenario, s])
+        if not tables.slice_has_req[scenario, s] or n == 0 or not tables.slice_traffic[scenario, s] > 0:
+            continue
+        ues = tables.slice_ues[scenario, s, :n]
+        out[ues] = poisson_from_tables(cdf[scenario, s], u[ues]).astype(np.float64) * 1e6
+    return out
+
+
 def make_cfg(S, U, R, G, Us, bandwidth_hz=100e6, hist_depth=10, max_age_cap=400, max_steps=1000,
              overfulfill=0.2, norm_traffic=120.0, norm_ues=5.0, norm_se=40.0) -> _Cfg:
     return _Cfg(S, U, R, G, Us, hist_depth, max_age_cap, max_steps, bandwidth_hz, overfulfill,

@@ -1,0 +1,79 @@
+"""bench.py's rank logic without a GPU: world-size-2 gloo run of the shard ranges, per-rank seeds, the barrier + sync
+bracket, the MAX-over-ranks clock, the metrics all_gather and the JSON line, with a stub env in place of the HIP one."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import json, os, sys, time, types
+sys.path.insert(0, os.environ["REPO"])
+import torch, torch.distributed as dist
+import bench
+from intent_radio_sched_multi_slice_amd.dist import gather_metrics, local_metrics, shard_range, summarize
+world, rank, local_rank = bench.rank_env()
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, U, S, K = 8, 5, 3, 7
+lo, hi = shard_range(B * world, rank, world)
+assert hi - lo == B
+class StubEnv:
+    def __init__(self):
+        g = torch.Generator().manual_seed(10 + 31 * (rank + 1))
+        self.reward = torch.rand((B, S + 1), generator=g, dtype=torch.float64) - 0.5
+        self.done = torch.zeros(B, dtype=torch.uint8)
+        self.n = 0
+        z = lambda: torch.ones((B, U), dtype=torch.int32) * (rank + 1)
+        self._v = {"pkt_effective_thr": z(), "dropped_pkts": z(), "pkt_incoming": z() * 2, "queue_pkts": z()}
+    def step(self):
+        self.n += 1
+        time.sleep(0.002 * (rank + 1))          # rank 1 is slower: the MAX must pick it up
+    def views(self): return self._v
+env = StubEnv()
+def max_over_ranks(x):
+    t = torch.tensor([x], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); return float(t.item())
+elapsed = bench.timed_steps(env.step, K, lambda: None, dist.barrier, max_over_ranks)
+assert env.n == K
+gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
+assert gathered.shape == (world, 8)
+args = types.SimpleNamespace(steps=K, warmup=2, config=2, traces=4, trace_len=5)
+line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, elapsed, {"ranenv_core_kernel<STEP>": 0.5, "n_steps": K}, None,
+                        summarize(gathered))
+if rank == 0:
+    print("LINE " + json.dumps(line), flush=True)
+print(f"RANK {rank} elapsed {elapsed!r} lo {lo} hi {hi}", flush=True)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_bench_rank_logic_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() % 2000)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("LINE ")]
+    ranks = sorted(l for l in out.stdout.splitlines() if l.startswith("RANK "))
+    assert len(lines) == 1 and len(ranks) == 2
+    line = json.loads(lines[0][5:])
+    K, B, world = 7, 8, 2
+    e0, e1 = (float(r.split()[3]) for r in ranks)
+    assert e0 == e1                                             # both ranks report the MAX over ranks ...
+    assert e0 >= K * 0.004                                      # ... which is the slow rank's time
+    assert ranks[0].endswith("lo 0 hi 8") and ranks[1].endswith("lo 8 hi 16")
+    assert line["n_gpus"] == world and line["steps"] == K and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(B * world * K / e0, rel=1e-9)          # whole-job aggregate
+    assert line["ms_per_step"] == pytest.approx(e0 / K * 1e3, rel=1e-9)
+    rf = line["roofline"]
+    assert rf["frac"] == pytest.approx(line["value"] / world * 1000 / 8e12, rel=1e-9)   # same clock as value, per GPU
+    assert rf["dominant_kernel"]["ms"] == 0.5 and rf["traffic"] is None
+    m = line["metrics"]
+    assert m["env_steps"] == B * K * world and m["pkts_sent"] == B * 5 * (1 + 2) and m["pkts_incoming"] == 2 * m["pkts_sent"]
+    assert line["config"]["global_batch"] == B * world

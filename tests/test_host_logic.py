@@ -252,3 +252,27 @@ def test_quadriga_channel_plugin_with_a_fake_hdf5_file(tmp_path, monkeypatch):
     except ImportError:
         with pytest.raises(ImportError, match="needs h5py"):
             plugins.QuadrigaChannel(U, 1, np.array([R]), None, str(tmp_path), "x").step(0, 0, None)
+
+
+def test_create_rejects_row_lengths_the_pairwise_plan_cannot_follow():
+    """numpy's pairwise sum splits a row until every leaf is <= 128; the kernel follows two levels, so R in [489, 512]
+    with a quarter above 128 (e.g. 500 -> 120/128/120/132) must be refused at create, not summed in another order."""
+    import ctypes as C
+    from intent_radio_sched_multi_slice_amd import _lib
+    lib = _lib.load()
+
+    def create(R):
+        cfg = _lib.Config(_lib.ABI_VERSION, 0, 4, 5, 25, R, 1, 5, 10, 400, 100, 1, 0, 0, 100e6, 0.2, 120.0, 5.0, 40.0)
+        h = C.c_void_p()
+        st = lib.ranenv_create(C.byref(cfg), C.byref(h))
+        msg = (lib.ranenv_last_error(None) or b"").decode()
+        if st == 0:
+            lib.ranenv_destroy(h)
+        return st, msg
+
+    for R in (490, 500, 511):
+        st, msg = create(R)
+        assert st == -1 and "pairwise" in msg, (R, st, msg)
+    for R in (488, 512):                       # valid plans: fail later (no GPU here) or succeed, but not on the size check
+        st, msg = create(R)
+        assert "pairwise" not in msg, (R, msg)
