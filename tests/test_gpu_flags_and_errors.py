@@ -136,7 +136,7 @@ def test_errors_are_reported_not_swallowed():
         env.set_episodes(scenario=np.array([0, 0]), se_base=np.array([0, 3]), se_len=2)
     env.set_episodes(scenario=np.array([0, 0]), se_base=np.array([0, 2]), se_len=2)
     env.reset()
-    with pytest.raises(RanEnvError, match="no traffic given and no traffic pool bound"):
+    with pytest.raises(RanEnvError, match="no traffic given, no traffic pool bound and no traffic generator set"):
         env.step()
     env.bind_traffic_pool(torch.zeros((2, 9), dtype=torch.int32, device=env.device))
     env.set_episodes(scenario=np.array([0, 0]), se_base=np.array([0, 2]), se_len=2, trf_base=np.array([0, 1]), trf_len=1)
@@ -146,6 +146,25 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(RanEnvError, match="expected shape"):
         env.step(np.zeros((2, 4)), np.zeros((2, 3), dtype=np.uint8))
     env.step(np.zeros((2, 3)), np.zeros((2, 3), dtype=np.uint8))     # and a good call still works
+    # episode advance / traffic generator misuse
+    with pytest.raises(RanEnvError, match="no episode table"):
+        env.enable_autoreset(0, 2)
+    with pytest.raises(RanEnvError, match="exceeds the bound pool"):
+        env.set_episode_table(scenario=[0, 0], se_base=[0, 3], se_len=2)
+    env.set_episode_table(scenario=[0, 0], se_base=[0, 2], se_len=2, first_episode=4)
+    with pytest.raises(RanEnvError, match="inside the table"):
+        env.enable_autoreset(0, 2)
+    with pytest.raises(RanEnvError, match="max_steps must be >= 1"):
+        env.set_max_steps([3, 0])
+    env.enable_autoreset(4, 6, episode_numbers=[4, 5])
+    env.step(np.zeros((2, 3)), np.zeros((2, 3), dtype=np.uint8))
+    env.disable_autoreset()
+    hot = copy_tabs = generate_scaled_scenarios(1, seed=1, n_slices=3, n_ues=9, max_ues_slice=3, min_slices=2, min_ues=1)
+    hot.slice_traffic[0, hot.slice_has_req[0] != 0] = 500.0
+    env.set_traffic_generator(1)
+    with pytest.raises(RanEnvError, match="outside \\(0, 128\\]"):
+        env.load_scenarios(hot)
+    env.load_scenarios(tabs)
     # a scenario row that is not self-consistent is refused at load time
     import copy
     broken = copy.deepcopy(tabs)

@@ -11,8 +11,8 @@ run() {  # name timeout cmd...
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name was killed: stopping"; exit 1; fi
   return $rc
 }
-run pytest 900 python -m pytest tests -x -q -m gpu
+run pytest 900 python -m pytest tests -q -m gpu --maxfail=${MAXFAIL:-6}
 for lm in ${LATE_MODES:-}; do RANENV_LATE=$lm run pytest_late$lm 900 python -m pytest tests -x -q -m gpu; done
 if [ "$#" -gt 0 ]; then run ab 600 python tools/abprobe.py "$@"; fi
-if [ -f tools/variants/stamps.so ]; then RANENV_LIB=$PWD/tools/variants/stamps.so run stamps 300 python tools/stamps.py; fi
+if [ -n "${STAMPS:-}" ] && [ -f tools/variants/stamps.so ]; then RANENV_LIB=$PWD/tools/variants/stamps.so run stamps 300 python tools/stamps.py; fi
 exit 0
