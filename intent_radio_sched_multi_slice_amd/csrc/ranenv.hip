@@ -368,16 +368,21 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
 constexpr int CORE_NT = GRP * GRP;   // 256 = largest U
 
 struct SharedCore {
-    double rows[GRP][4][GRP];     // per slice, by UE position: allocation scratch, then drift x3 + mean SE for (3)
+    // per slice 4 rows of 16 doubles by UE position: allocation scratch, then drift x3 + mean SE for (3).  The lanes of
+    // a wave belong to different slices and read the same position of their own slice's row: the 2-double pad puts
+    // the slices 4 banks apart instead of on one bank (16-byte alignment of the rows kept for 128-bit LDS reads)
+    double rows[GRP][4 * GRP + 2];
     double xr[4][GRP];            // cross-slice rows
     double pf[GRP][3];            // param value                     } slice tables of this env's scenario
     double sf[GRP][2];            // priority, traffic               }
     int si[GRP][8];               // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
     int pi[GRP][6];               // (metric, op) x 3
-    int cnt[GRP][GRP];            // RBs of each slot
-    int flg[GRP][GRP];            // buffer-not-empty flag of each slot
+    int cnt[GRP][GRP + 4];        // RBs of each slot (padded like rows)
+    int flg[GRP][GRP + 4];        // buffer-not-empty flag of each slot
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
 };
+
+DEVFN double *srow(SharedCore &sh, int s, int k) { return &sh.rows[s][k * GRP]; }
 
 // Role (0).  Called by every thread of the workgroup (it contains barriers); `have` = this thread's UE is
 // in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
@@ -391,7 +396,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     const int tid = threadIdx.x, S = p.S;
     const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
     const int sl = have ? slc : 0;                 // idle threads read row 0 and write nothing
-    double *r0 = sh.rows[sl][0], *r1 = sh.rows[sl][1], *r2 = sh.rows[sl][2], *r3 = sh.rows[sl][3];
+    double *r0 = srow(sh, sl, 0), *r1 = srow(sh, sl, 1), *r2 = srow(sh, sl, 2), *r3 = srow(sh, sl, 3);
     int choice = p.fixed_intra;                    // requested now, used after the inter-slice part
     if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && have) ? (int)p.intra[(size_t)e * S + sl] : RANENV_INTRA_RR;
     const double occ = (double)q / (double)mp;
@@ -411,8 +416,8 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             double occ_mb = 0.0, thr_mb = 0.0;
             if (ok1 && active) {
                 const double pkt = (double)msg, bmax = (double)bsize;
-                occ_mb = ((np_sum16_lds(sh.rows[s1][0], nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
-                thr_mb = ((np_sum16_lds(sh.rows[s1][1], nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+                occ_mb = ((np_sum16_lds(srow(sh, s1, 0), nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
+                thr_mb = ((np_sum16_lds(srow(sh, s1, 1), nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
             }
             if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
             wave_sync();
@@ -567,7 +572,7 @@ template <int MODE>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
     __shared__ SharedCore sh;
-    auto &rows = sh.rows; auto &xr = sh.xr;
+    auto &xr = sh.xr;
     const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
     if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
@@ -646,8 +651,8 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     se1.init(tile, U, u, R);                       // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // zero the per-slice rows, park the tables
-    for (int i = tid; i < GRP * 4 * GRP; i += (int)blockDim.x) (&rows[0][0][0])[i] = 0.0;
-    for (int i = tid; i < GRP * GRP; i += (int)blockDim.x) { (&sh.cnt[0][0])[i] = 0; (&sh.flg[0][0])[i] = 0; }
+    for (int i = tid; i < GRP * (4 * GRP + 2); i += (int)blockDim.x) (&sh.rows[0][0])[i] = 0.0;
+    for (int i = tid; i < GRP * (GRP + 4); i += (int)blockDim.x) { (&sh.cnt[0][0])[i] = 0; (&sh.flg[0][0])[i] = 0; }
     if (tid < S * 8) (&sh.si[0][0])[tid] = st_si;
     if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi;
     if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
@@ -838,8 +843,8 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
 
         if (slc >= 0) {
             // rows for this TTI's observation
-            rows[slc][0][ue_pos] = dres[0]; rows[slc][1][ue_pos] = dres[1]; rows[slc][2][ue_pos] = dres[2];
-            rows[slc][3][ue_pos] = se_mean_new;
+            srow(sh, slc, 0)[ue_pos] = dres[0]; srow(sh, slc, 1)[ue_pos] = dres[1]; srow(sh, slc, 2)[ue_pos] = dres[2];
+            srow(sh, slc, 3)[ue_pos] = se_mean_new;
             sh.cnt[slc][ue_pos] = rb_count;
             if (p.obs_intra && ue_pos < Us) {                                          // per-UE entries (:186-200)
                 float *oa = p.obs_intra + ((size_t)e * S + slc) * W;
@@ -879,7 +884,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
             for (int qi = 0; qi < 3; qi++) {
                 if (qi < npar) {
                     const int m = sh.pi[s][2 * qi];
-                    const double mean = np_sum16_lds(rows[s][m], n) / (double)n;
+                    const double mean = np_sum16_lds(srow(sh, s, m), n) / (double)n;
                     sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
                 }
             }
@@ -893,7 +898,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
             am[m] = undeclared ? 0.0 : 1.0;
             sv[m] = undeclared ? 0.0 : sv[m];
         }
-        const double se_slice = n > 0 ? np_sum16_lds(rows[s][3], n) / (double)n : 0.0;   // :146-157
+        const double se_slice = n > 0 ? np_sum16_lds(srow(sh, s, 3), n) / (double)n : 0.0;   // :146-157
         const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
         const float tr = (float)(traffic_req / p.norm_traffic), nu = (float)((double)n / p.norm_ues);
