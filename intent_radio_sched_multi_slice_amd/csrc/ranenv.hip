@@ -566,7 +566,11 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
 #ifndef RANENV_WAVES_PER_EU   /* waves per SIMD the step kernel is compiled for: 4 = 128 VGPRs, 8 workgroups of 2 waves per CU */
 #define RANENV_WAVES_PER_EU 4
 #endif
+#if RANENV_WAVES_PER_EU > 0
 #define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
+#else
+#define RANENV_CORE_ATTR
+#endif
 
 template <int MODE>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)

@@ -26,3 +26,7 @@ step bench 600 python3 bench.py
 step bench_driver 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
 step bench_cfg1 300 python3 bench.py --config 1 --no-cpu-baseline
 step bench_cfg4 300 python3 bench.py --config 4 --no-cpu-baseline
+if [ -f tools/variants/stamps.so ]; then
+  RANENV_LIB=$PWD/tools/variants/stamps.so RANENV_LATE=0 step stamps_late0 300 python3 tools/stamps.py
+  RANENV_LIB=$PWD/tools/variants/stamps.so step stamps_late1 300 python3 tools/stamps.py
+fi
