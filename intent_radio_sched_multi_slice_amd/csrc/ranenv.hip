@@ -206,7 +206,7 @@ DEVFN RowPlan make_row_plan(int n)
 }
 
 #ifndef RANENV_SE_DEPTH
-#define RANENV_SE_DEPTH 2
+#define RANENV_SE_DEPTH 4
 #endif
 #ifndef RANENV_LATE_DEFAULT
 #define RANENV_LATE_DEFAULT 1
@@ -243,8 +243,11 @@ struct SeStream {
 // exactly, so the result is numpy's bit for bit while the loop body stays branch-free; the only
 // control flow per 8-group is one wave-uniform "leaf finished?" test.  Only the row's last leaf can
 // have a tail (R mod 8 elements); it is added sequentially after the loop, as numpy does.
-template <typename InFn>
-DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
+// `after_issue` runs once, before the last turn of the queue (no load is requested in that turn): what the caller
+// loads there completes behind the tile (loads retire in order) while the last groups are being summed, and needs
+// no register during the rest of the stream.
+template <typename InFn, typename Hook>
+DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part, Hook after_issue)
 {
     const RowPlan pl = make_row_plan(R);
     const int tail = R & 7, G = R >> 3;
@@ -301,8 +304,11 @@ DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part)
             }
         }
     };
+    const int last = G > 0 ? ((G - 1) / SE_NQ) * SE_NQ : 0;      // first group of the last turn
 #pragma unroll 1
-    for (int gi = 0; gi < G; gi += SE_NQ) pass(gi);
+    for (int gi = 0; gi < last; gi += SE_NQ) pass(gi);
+    after_issue();
+    if (G > 0) pass(last);
     if (tail > 0) {
         const int m = G % SE_NQ;
 #pragma unroll
@@ -567,7 +573,11 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
 #define RANENV_WAVES_PER_EU 4
 #endif
 #if RANENV_WAVES_PER_EU > 0
+#if RANENV_WAVES_PER_EU > 0
 #define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
+#else
+#define RANENV_CORE_ATTR
+#endif
 #else
 #define RANENV_CORE_ATTR
 #endif
@@ -620,11 +630,31 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     double sem_prev = 0.0;
-    if (MODE != MODE_RESET) {
-        total = p.st.queue_pkts[su]; sum_age = p.st.queue_age_sum[su];
-        front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
-    }
-    if (!clear_hist) { win_sent = p.st.win_sent[su]; win_drop = p.st.win_dropped[su]; }
+#ifndef RANENV_DEFER_STATE
+#define RANENV_DEFER_STATE 2   /* the part of the UE state the allocation does not need is requested 0: at kernel entry, 1: when
+                                  the tile's last load has been requested, 2: after the stream (default: 14 registers fewer
+                                  while the tile streams pay for 32 instead of 16 loads in flight per lane; measured A/B) */
+#endif
+    if (MODE != MODE_RESET) total = p.st.queue_pkts[su];
+    if (!clear_hist) win_sent = p.st.win_sent[su];
+    int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
+    int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
+    int old_s = 0, old_d = 0;
+    double traffic = 0.0;
+    const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
+    auto rest_of_state = [&]() {
+        if (MODE != MODE_RESET) {
+            sum_age = p.st.queue_age_sum[su];
+            front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
+        }
+        if (!clear_hist) win_drop = p.st.win_dropped[su];
+        if (hlen == D) { old_s = *rs; old_d = *rd; }
+        if (MODE != MODE_RESET && !gen_traffic)
+            traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
+    };
+#if !RANENV_DEFER_STATE
+    rest_of_state();
+#endif
     if (MODE == MODE_STEP) sem_prev = p.st.se_mean[su];
     // the scenario's slice tables, one element per thread (blockDim >= 8*S), parked in LDS below
     int st_si = 0, st_pi = 0; double st_pf = 0.0, st_sf = 0.0;
@@ -641,14 +671,6 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         if (tid < S) p.st.policy_scores[(size_t)e * S + tid] = p.st.next_scores[(size_t)e * S + tid];
 #endif
     }
-    int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
-    int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
-    int old_s = 0, old_d = 0;
-    if (hlen == D) { old_s = *rs; old_d = *rd; }
-    double traffic = 0.0;
-    const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
-    if (MODE != MODE_RESET && !gen_traffic)
-        traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
     const int episode_no = gen_traffic ? uni(p.st.episode_no[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
     SeStream se1;
@@ -672,21 +694,29 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
     double my_full = 0.0, my_part = 0.0;
+    auto hook = [&]() {
+#if RANENV_DEFER_STATE == 1
+        rest_of_state();
+#endif
+    };
     if (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1
         my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
 #elif RANENV_DIAG == 2
-        row_sums(se1, R, [=](int r) { return false; }, my_full, my_part); my_part = (double)(us1 + uc1);
+        row_sums(se1, R, [=](int r) { return false; }, my_full, my_part, hook); my_part = (double)(us1 + uc1);
 #else
-        row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part);
+        row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part, hook);
 #endif
     } else if (MODE == MODE_DENSE) {
         const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-        row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part);
+        row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part, hook);
     } else {
-        row_sums(se1, R, [](int) { return false; }, my_full, my_part);
+        row_sums(se1, R, [](int) { return false; }, my_full, my_part, hook);
     }
+#if RANENV_DEFER_STATE == 2
+    rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
+#endif
     RANENV_STAMP(3);
     __syncthreads();        // every thread is done with the allocation's use of the per-slice rows
     RANENV_STAMP(4);
