@@ -54,31 +54,79 @@ enum { MODE_STEP = 0, MODE_DENSE = 1, MODE_RESET = 2 };
 // ---------------------------------------------------------------------------------------------
 // kernel parameters
 // ---------------------------------------------------------------------------------------------
+// The handle's arrays are few allocations ("slabs") with many equally shaped fields each (field k of a slab at
+// k * stride): one base pointer per slab in the kernel arguments instead of one per field.  50 pointers cost 100
+// SGPRs, more than a wave has; the step kernel kept spilling them to VGPR lanes and reading them back.
 struct Tables {  // scenario pool on the device, rows of [n_scenarios]
     int32_t *slice_i32;  // [NS][S][8] active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
     double  *slice_f64;  // [NS][S][2] priority, traffic
     int32_t *param_i32;  // [NS][S][3][2] metric, op
     double  *param_f64;  // [NS][S][3]
     int32_t *slice_ues;  // [NS][S][Us]
-    int32_t *slot_ue, *slot_mp, *slot_pk;   // [NS][S*16] UE id (-1 = empty slot), its max_pkts / pkt_size
+    int32_t *slot;       // [3][NS][S*16] slot_ue (UE id, -1 = empty slot), slot_mp, slot_pk (its max_pkts / pkt_size)
     int32_t *slice_usecase;                 // [NS][S] SchedColORAN: bit 0 eMBB, bit 1 URLLC
-    int32_t *ue_slice, *ue_pos, *ue_pkt_size, *ue_max_pkts, *ue_max_age;  // [NS][U]
+    int32_t *ue;         // [5][NS][U] ue_slice, ue_pos, ue_pkt_size, ue_max_pkts, ue_max_age
 };
 
 struct State {
-    int32_t *queue_pkts; int64_t *queue_age_sum; int32_t *front; int32_t *front_rem; int32_t *fifo;
-    int64_t *win_sent; int64_t *win_dropped; double *se_mean;
+    int32_t *u4;         // [12][B][U] 4-byte per-UE fields (the ST_* accessors below name them)
+    int64_t *u8;         // [4][B][U]  8-byte per-UE fields: queue_age_sum, win_sent, win_dropped (int64), se_mean (double)
+    int32_t *b4;         // [8][B]     per-env counters
     int2 *age_ring; int32_t *ring_sent; int32_t *ring_drop;
-    int32_t *hist_len; int32_t *n_push; int32_t *step_no; int32_t *se_pos; int32_t *trf_pos;
-    int32_t *pkt_incoming, *pkt_throughputs, *pkt_effective_thr, *dropped_pkts, *rb_start, *rb_count;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
-    // allocation made at the end of a step for the next one (device policy): valid while alloc_gen[e] == KP::alloc_gen
-    int32_t *alloc_gen, *next_rb_start, *next_rb_count; double *next_scores;
-    int32_t *episode_no, *reset_count;      // [B] episode number an env is playing / resets it went through (auto-reset)
+    double *next_scores; // with next_rb_start / next_rb_count: the allocation made at the end of a step for the next one
+                         // (device policy), valid while alloc_gen[e] == KP::alloc_gen
 };
+enum { N_U4 = 12, N_U8 = 4, N_B4 = 8 };
+#define ST_queue_pkts(p) ((p).st.u4 + (size_t)(0) * (size_t)(p).BU)
+#define ST_front(p) ((p).st.u4 + (size_t)(1) * (size_t)(p).BU)
+#define ST_front_rem(p) ((p).st.u4 + (size_t)(2) * (size_t)(p).BU)
+#define ST_fifo(p) ((p).st.u4 + (size_t)(3) * (size_t)(p).BU)
+#define ST_pkt_incoming(p) ((p).st.u4 + (size_t)(4) * (size_t)(p).BU)
+#define ST_pkt_throughputs(p) ((p).st.u4 + (size_t)(5) * (size_t)(p).BU)
+#define ST_pkt_effective_thr(p) ((p).st.u4 + (size_t)(6) * (size_t)(p).BU)
+#define ST_dropped_pkts(p) ((p).st.u4 + (size_t)(7) * (size_t)(p).BU)
+#define ST_rb_start(p) ((p).st.u4 + (size_t)(8) * (size_t)(p).BU)
+#define ST_rb_count(p) ((p).st.u4 + (size_t)(9) * (size_t)(p).BU)
+#define ST_next_rb_start(p) ((p).st.u4 + (size_t)(10) * (size_t)(p).BU)
+#define ST_next_rb_count(p) ((p).st.u4 + (size_t)(11) * (size_t)(p).BU)
+#define ST_queue_age_sum(p) ((int64_t *)((p).st.u8 + (size_t)(0) * (size_t)(p).BU))
+#define ST_win_sent(p) ((int64_t *)((p).st.u8 + (size_t)(1) * (size_t)(p).BU))
+#define ST_win_dropped(p) ((int64_t *)((p).st.u8 + (size_t)(2) * (size_t)(p).BU))
+#define ST_se_mean(p) ((double *)((p).st.u8 + (size_t)(3) * (size_t)(p).BU))
+#define ST_hist_len(p) ((p).st.b4 + (size_t)(0) * (size_t)(p).B)
+#define ST_n_push(p) ((p).st.b4 + (size_t)(1) * (size_t)(p).B)
+#define ST_step_no(p) ((p).st.b4 + (size_t)(2) * (size_t)(p).B)
+#define ST_se_pos(p) ((p).st.b4 + (size_t)(3) * (size_t)(p).B)
+#define ST_trf_pos(p) ((p).st.b4 + (size_t)(4) * (size_t)(p).B)
+#define ST_alloc_gen(p) ((p).st.b4 + (size_t)(5) * (size_t)(p).B)
+#define ST_episode_no(p) ((p).st.b4 + (size_t)(6) * (size_t)(p).B)
+#define ST_reset_count(p) ((p).st.b4 + (size_t)(7) * (size_t)(p).B)
+#define ST_age_ring(p) ((p).st.age_ring)
+#define ST_ring_sent(p) ((p).st.ring_sent)
+#define ST_ring_drop(p) ((p).st.ring_drop)
+#define ST_mask_inter(p) ((p).st.mask_inter)
+#define ST_mask_intra(p) ((p).st.mask_intra)
+#define ST_policy_scores(p) ((p).st.policy_scores)
+#define ST_next_scores(p) ((p).st.next_scores)
+#define TB_ue_slice(p) ((p).tab.ue + (size_t)(0) * (size_t)(p).NSU)
+#define TB_ue_pos(p) ((p).tab.ue + (size_t)(1) * (size_t)(p).NSU)
+#define TB_ue_pkt_size(p) ((p).tab.ue + (size_t)(2) * (size_t)(p).NSU)
+#define TB_ue_max_pkts(p) ((p).tab.ue + (size_t)(3) * (size_t)(p).NSU)
+#define TB_ue_max_age(p) ((p).tab.ue + (size_t)(4) * (size_t)(p).NSU)
+#define TB_slot_ue(p) ((p).tab.slot + (size_t)(0) * (size_t)(p).NSL)
+#define TB_slot_mp(p) ((p).tab.slot + (size_t)(1) * (size_t)(p).NSL)
+#define TB_slot_pk(p) ((p).tab.slot + (size_t)(2) * (size_t)(p).NSL)
+#define TB_slice_i32(p) ((p).tab.slice_i32)
+#define TB_slice_f64(p) ((p).tab.slice_f64)
+#define TB_param_i32(p) ((p).tab.param_i32)
+#define TB_param_f64(p) ((p).tab.param_f64)
+#define TB_slice_ues(p) ((p).tab.slice_ues)
+#define TB_slice_usecase(p) ((p).tab.slice_usecase)
 
 struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
+    long long BU, NSU, NSL;   // slab strides: B*U, n_scenarios*U, n_scenarios*S*16
     int e0;   // first env of this launch
     int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
     int late;        // 0: every step allocates at its head; 1: a hashed half of the envs, 2: all envs allocate for the next
@@ -119,24 +167,36 @@ DEVFN bool d_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * 
 // an instruction costs the same with one active lane as with 64.
 DEVFN double np_sum16_lds(const double *row, int n)
 {
-    double x[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) x[j] = row[j];
+    // The two halves of the row are read one after the other, so that 8 (not 16) doubles are alive at a time in the
+    // common shapes; only numpy's n == 16 shape pairs element j with element 8 + j and re-reads the first half.
     double res = 0.0;
+    double x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = row[j];
+    double t8 = 0.0;
     if (__builtin_amdgcn_ballot_w64(n < 8) != 0) {
         const double seq = ((((((x[0] + x[1]) + x[2]) + x[3]) + x[4]) + x[5]) + x[6]) + x[7];
         res = n < 8 ? seq : res;
     }
-    if (__builtin_amdgcn_ballot_w64(n >= 8 && n < 16) != 0) {
-        double t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    const bool mid = n >= 8 && n < 16;
+    if (__builtin_amdgcn_ballot_w64(mid) != 0)
+        t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    if (__builtin_amdgcn_ballot_w64(n >= 8) != 0) {
+        double y[8];
 #pragma unroll
-        for (int j = 8; j < 15; j++) t8 += x[j];
-        res = (n >= 8 && n < 16) ? t8 : res;
-    }
-    if (__builtin_amdgcn_ballot_w64(n >= 16) != 0) {
-        const double t16 = (((x[0] + x[8]) + (x[1] + x[9])) + ((x[2] + x[10]) + (x[3] + x[11]))) +
-                           (((x[4] + x[12]) + (x[5] + x[13])) + ((x[6] + x[14]) + (x[7] + x[15])));
-        res = n >= 16 ? t16 : res;
+        for (int j = 0; j < 8; j++) y[j] = row[8 + j];
+        if (__builtin_amdgcn_ballot_w64(mid) != 0) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) t8 += y[j];
+            res = mid ? t8 : res;
+        }
+        if (__builtin_amdgcn_ballot_w64(n >= 16) != 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = row[j];
+            const double t16 = (((x[0] + y[0]) + (x[1] + y[1])) + ((x[2] + y[2]) + (x[3] + y[3]))) +
+                               (((x[4] + y[4]) + (x[5] + y[5])) + ((x[6] + y[6]) + (x[7] + y[7])));
+            res = n >= 16 ? t16 : res;
+        }
     }
     return res;
 }
@@ -206,7 +266,13 @@ DEVFN RowPlan make_row_plan(int n)
 }
 
 #ifndef RANENV_SE_DEPTH
-#define RANENV_SE_DEPTH 4
+#define RANENV_SE_DEPTH 1
+#endif
+#ifndef RANENV_DEFER_STATE
+#define RANENV_DEFER_STATE 2   /* the part of the UE state the allocation does not need is requested 0: at kernel entry, 1: before
+                                  the queue's last turn, 2: after the stream (default: ~20 registers fewer while the tile
+                                  streams; with 8 loads in flight per lane the kernel fits 96 VGPRs = 5 waves per SIMD
+                                  without spills; measured A/B in profiles/r02_ab_log.txt) */
 #endif
 #ifndef RANENV_LATE_DEFAULT
 #define RANENV_LATE_DEFAULT 1
@@ -348,7 +414,7 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
 #if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of thread 0 at up to S phase boundaries of the step
                           kernel, dumped into policy_scores[e][k] instead of the scores (tools/stamps.py) */
 #define RANENV_STAMP(k) do { if (threadIdx.x == 0 && (k) < p.S) \
-    p.st.policy_scores[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+    ST_policy_scores(p)[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RANENV_STAMP(k) do { } while (0)
 #endif
@@ -423,6 +489,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             if (ok1 && active) {
                 const double pkt = (double)msg, bmax = (double)bsize;
                 occ_mb = ((np_sum16_lds(srow(sh, s1, 0), nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
+                asm volatile("" : "+v"(occ_mb));     // one row at a time: both rows in registers at once set the kernel's VGPR peak
                 thr_mb = ((np_sum16_lds(srow(sh, s1, 1), nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
             }
             if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
@@ -569,8 +636,9 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     rb_count = have ? count : 0;
 }
 
-#ifndef RANENV_WAVES_PER_EU   /* waves per SIMD the step kernel is compiled for: 4 = 128 VGPRs, 8 workgroups of 2 waves per CU */
-#define RANENV_WAVES_PER_EU 4
+#ifndef RANENV_WAVES_PER_EU   /* waves per SIMD the step kernel is compiled for: 5 = 96 VGPRs, 10 workgroups of 2 waves per CU
+                                 (4 = 128 VGPRs, 8 workgroups; 0 = whatever the compiler takes) */
+#define RANENV_WAVES_PER_EU 5
 #endif
 #if RANENV_WAVES_PER_EU > 0
 #if RANENV_WAVES_PER_EU > 0
@@ -604,12 +672,12 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     ep.se_len = uni(ep.se_len); ep.trf_len = uni(ep.trf_len);
     ep.se_base = uni64(ep.se_base); ep.trf_base = uni64(ep.trf_base);
     const int sc = ep.scenario;
-    const int t = (MODE == MODE_RESET) ? 0 : uni(p.st.step_no[e]);
-    int hlen = uni(p.st.hist_len[e]);
-    const int npush = uni(p.st.n_push[e]);                    // kept in [0, D)
+    const int t = (MODE == MODE_RESET) ? 0 : uni(ST_step_no(p)[e]);
+    int hlen = uni(ST_hist_len(p)[e]);
+    const int npush = uni(ST_n_push(p)[e]);                    // kept in [0, D)
     // a position persisted under an older, longer trace must not index past the current one
-    int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(p.st.se_pos[e]);
-    int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(p.st.trf_pos[e]);
+    int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(ST_se_pos(p)[e]);
+    int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(ST_trf_pos(p)[e]);
     se_pos = se_pos < ep.se_len ? se_pos : 0;
     trf_pos = trf_pos < ep.trf_len ? trf_pos : 0;
     const int hlen_old = hlen;                                // window length the allocation sees
@@ -625,29 +693,24 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     const bool act = tid < U;
     const int u = act ? tid : U - 1;
     const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
-    const int slc = p.tab.ue_slice[tu], ue_pos = p.tab.ue_pos[tu];
-    const int pkt_size = p.tab.ue_pkt_size[tu], max_pkts = p.tab.ue_max_pkts[tu], max_age = p.tab.ue_max_age[tu];
+    const int slc = TB_ue_slice(p)[tu], ue_pos = TB_ue_pos(p)[tu];
+    const int pkt_size = TB_ue_pkt_size(p)[tu], max_pkts = TB_ue_max_pkts(p)[tu], max_age = TB_ue_max_age(p)[tu];
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     double sem_prev = 0.0;
-#ifndef RANENV_DEFER_STATE
-#define RANENV_DEFER_STATE 2   /* the part of the UE state the allocation does not need is requested 0: at kernel entry, 1: when
-                                  the tile's last load has been requested, 2: after the stream (default: 14 registers fewer
-                                  while the tile streams pay for 32 instead of 16 loads in flight per lane; measured A/B) */
-#endif
-    if (MODE != MODE_RESET) total = p.st.queue_pkts[su];
-    if (!clear_hist) win_sent = p.st.win_sent[su];
-    int32_t *rs = p.st.ring_sent + ((size_t)e * D + npush) * U + u;
-    int32_t *rd = p.st.ring_drop + ((size_t)e * D + npush) * U + u;
+    if (MODE != MODE_RESET) total = ST_queue_pkts(p)[su];
+    if (!clear_hist) win_sent = ST_win_sent(p)[su];
+    int32_t *rs = ST_ring_sent(p) + ((size_t)e * D + npush) * U + u;
+    int32_t *rd = ST_ring_drop(p) + ((size_t)e * D + npush) * U + u;
     int old_s = 0, old_d = 0;
     double traffic = 0.0;
     const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
     auto rest_of_state = [&]() {
         if (MODE != MODE_RESET) {
-            sum_age = p.st.queue_age_sum[su];
-            front = p.st.front[su]; front_rem = p.st.front_rem[su]; fifo = p.st.fifo[su];
+            sum_age = ST_queue_age_sum(p)[su];
+            front = ST_front(p)[su]; front_rem = ST_front_rem(p)[su]; fifo = ST_fifo(p)[su];
         }
-        if (!clear_hist) win_drop = p.st.win_dropped[su];
+        if (!clear_hist) win_drop = ST_win_dropped(p)[su];
         if (hlen == D) { old_s = *rs; old_d = *rd; }
         if (MODE != MODE_RESET && !gen_traffic)
             traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
@@ -655,23 +718,23 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
 #if !RANENV_DEFER_STATE
     rest_of_state();
 #endif
-    if (MODE == MODE_STEP) sem_prev = p.st.se_mean[su];
+    if (MODE == MODE_STEP) sem_prev = ST_se_mean(p)[su];
     // the scenario's slice tables, one element per thread (blockDim >= 8*S), parked in LDS below
     int st_si = 0, st_pi = 0; double st_pf = 0.0, st_sf = 0.0;
-    if (tid < S * 8) st_si = p.tab.slice_i32[(size_t)sc * S * 8 + tid];
-    if (tid < S * 6) st_pi = p.tab.param_i32[(size_t)sc * S * 6 + tid];
-    if (tid < S * 3) st_pf = p.tab.param_f64[(size_t)sc * S * 3 + tid];
-    if (tid < S * 2) st_sf = p.tab.slice_f64[(size_t)sc * S * 2 + tid];
+    if (tid < S * 8) st_si = TB_slice_i32(p)[(size_t)sc * S * 8 + tid];
+    if (tid < S * 6) st_pi = TB_param_i32(p)[(size_t)sc * S * 6 + tid];
+    if (tid < S * 3) st_pf = TB_param_f64(p)[(size_t)sc * S * 3 + tid];
+    if (tid < S * 2) st_sf = TB_slice_f64(p)[(size_t)sc * S * 2 + tid];
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
-    if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(p.st.alloc_gen[e]) == p.alloc_gen;
+    if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
     if (pre) {
-        rb_start = p.st.next_rb_start[su]; rb_count = p.st.next_rb_count[su];
+        rb_start = ST_next_rb_start(p)[su]; rb_count = ST_next_rb_count(p)[su];
 #if RANENV_DIAG != 9
-        if (tid < S) p.st.policy_scores[(size_t)e * S + tid] = p.st.next_scores[(size_t)e * S + tid];
+        if (tid < S) ST_policy_scores(p)[(size_t)e * S + tid] = ST_next_scores(p)[(size_t)e * S + tid];
 #endif
     }
-    const int episode_no = gen_traffic ? uni(p.st.episode_no[e]) : 0;
+    const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
     SeStream se1;
     se1.init(tile, U, u, R);                       // lane = UE: one dword per RB
@@ -689,7 +752,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
     if (MODE == MODE_STEP && !pre)
         alloc_front(p, sh, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
-                    rb_start, rb_count, p.st.policy_scores);
+                    rb_start, rb_count, ST_policy_scores(p));
     RANENV_STAMP(2);
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
@@ -775,7 +838,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
             // packets) entries in arrival order.  ring[k] holds entry k of a circular list (head index +
             // entry count per UE); only TTIs that admitted packets make an entry, so expiring / draining
             // costs one load per consumed entry and never a scan.
-            int2 *ring = p.st.age_ring + (size_t)e * L * U + u;
+            int2 *ring = ST_age_ring(p) + (size_t)e * L * U + u;
             int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
             auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
             auto load_head = [&]() { const int2 en = ring[(size_t)head * U]; front = en.x; front_rem = en.y; };
@@ -814,16 +877,16 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
         win_sent += sent - old_s; win_drop += dropped - old_d;
         *rs = (int32_t)sent; *rd = (int32_t)dropped;
-        p.st.queue_pkts[su] = total; p.st.queue_age_sum[su] = sum_age;
-        p.st.front[su] = front; p.st.front_rem[su] = front_rem; p.st.fifo[su] = fifo;
-        p.st.win_sent[su] = win_sent; p.st.win_dropped[su] = win_drop;
-        p.st.pkt_effective_thr[su] = (int32_t)sent; p.st.dropped_pkts[su] = (int32_t)dropped;
+        ST_queue_pkts(p)[su] = total; ST_queue_age_sum(p)[su] = sum_age;
+        ST_front(p)[su] = front; ST_front_rem(p)[su] = front_rem; ST_fifo(p)[su] = fifo;
+        ST_win_sent(p)[su] = win_sent; ST_win_dropped(p)[su] = win_drop;
+        ST_pkt_effective_thr(p)[su] = (int32_t)sent; ST_dropped_pkts(p)[su] = (int32_t)dropped;
         if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
-            p.st.pkt_incoming[su] = (int32_t)pkt_in; p.st.pkt_throughputs[su] = (int32_t)pkt_thr;
+            ST_pkt_incoming(p)[su] = (int32_t)pkt_in; ST_pkt_throughputs(p)[su] = (int32_t)pkt_thr;
         }
 
-        p.st.se_mean[su] = se_mean_new; sem_new = se_mean_new;
-        p.st.rb_start[su] = rb_start; p.st.rb_count[su] = rb_count;
+        ST_se_mean(p)[su] = se_mean_new; sem_new = se_mean_new;
+        ST_rb_start(p)[su] = rb_start; ST_rb_count(p)[su] = rb_count;
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
@@ -955,8 +1018,8 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         }
         if (p.reward) p.reward[(size_t)e * (S + 1) + s + 1] = cnt > 0 ? r : 0.0;
         if (MODE == MODE_RESET) {
-            p.st.mask_inter[(size_t)e * S + s] = (int8_t)active;
-            for (int k = 0; k < Us; k++) p.st.mask_intra[((size_t)e * S + s) * Us + k] = k < n ? 1 : 0;
+            ST_mask_inter(p)[(size_t)e * S + s] = (int8_t)active;
+            for (int k = 0; k < Us; k++) ST_mask_intra(p)[((size_t)e * S + s) * Us + k] = k < n ? 1 : 0;
         }
         // active_observations / slice_priorities indexed by slice (common.py:389-408)
         double mn = 0.0; int cntm = 0;
@@ -994,13 +1057,13 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         if (p.reward) p.reward[(size_t)e * (S + 1)] = rew;
         // per-env counters: everything was read as a scalar at kernel entry (hlen already reflects a cleared window)
         const int step_new = (MODE == MODE_RESET) ? 0 : t + 1;
-        p.st.step_no[e] = step_new;
-        p.st.hist_len[e] = hlen_new;
-        p.st.n_push[e] = npush + 1 == D ? 0 : npush + 1;
-        if (MODE == MODE_RESET) { p.st.se_pos[e] = ep.se_offset; p.st.trf_pos[e] = ep.trf_offset; }
+        ST_step_no(p)[e] = step_new;
+        ST_hist_len(p)[e] = hlen_new;
+        ST_n_push(p)[e] = npush + 1 == D ? 0 : npush + 1;
+        if (MODE == MODE_RESET) { ST_se_pos(p)[e] = ep.se_offset; ST_trf_pos(p)[e] = ep.trf_offset; }
         else {
-            p.st.se_pos[e] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
-            p.st.trf_pos[e] = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
+            ST_se_pos(p)[e] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
+            ST_trf_pos(p)[e] = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
         }
         const int max_steps_e = p.max_steps_env ? p.max_steps_env[e] : p.max_steps;
         if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= max_steps_e) ? 1 : 0;
@@ -1015,10 +1078,10 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
         __syncthreads();                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
         alloc_front(p, sh, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
-                    ns, nc, p.st.next_scores);
-        if (act) { p.st.next_rb_start[su] = ns; p.st.next_rb_count[su] = nc; }
+                    ns, nc, ST_next_scores(p));
+        if (act) { ST_next_rb_start(p)[su] = ns; ST_next_rb_count(p)[su] = nc; }
     }
-    if (tid == 0) p.st.alloc_gen[e] = late ? p.alloc_gen : 0;
+    if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
     RANENV_STAMP(8);
 }
 
@@ -1062,13 +1125,13 @@ __global__ void __launch_bounds__(CORE_NT) ranenv_head_kernel(const KP p)
     if (p.env_mask != nullptr && p.env_mask[e] == 0) return;
     const int S = p.S, U = p.U, D = p.D;
     const int sc = __builtin_amdgcn_readfirstlane(p.episodes[e].scenario);
-    const int hlen = __builtin_amdgcn_readfirstlane(p.st.hist_len[e]);      // counters after this TTI's push
-    const int npush = __builtin_amdgcn_readfirstlane(p.st.n_push[e]);
+    const int hlen = __builtin_amdgcn_readfirstlane(ST_hist_len(p)[e]);      // counters after this TTI's push
+    const int npush = __builtin_amdgcn_readfirstlane(ST_n_push(p)[e]);
     const int s = tid / GRP, pos = tid % GRP;
     const bool in_grid = s < S;
     const int NS16 = S * GRP;
     int ue = -1, mp = 1;
-    if (tid < NS16) { const size_t ts = (size_t)sc * NS16 + tid; ue = p.tab.slot_ue[ts]; mp = p.tab.slot_mp[ts]; }
+    if (tid < NS16) { const size_t ts = (size_t)sc * NS16 + tid; ue = TB_slot_ue(p)[ts]; mp = TB_slot_mp(p)[ts]; }
     const bool have = ue >= 0;
     const int gsh = (tid & 63) & ~(GRP - 1);
     const int n = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));
@@ -1077,33 +1140,33 @@ __global__ void __launch_bounds__(CORE_NT) ranenv_head_kernel(const KP p)
     double pv[3] = {0.0, 0.0, 0.0}, priority = 0.0, traffic_tab = 0.0;
     if (in_grid) {
         const size_t row = (size_t)sc * S + s;
-        const int32_t *si = p.tab.slice_i32 + row * 8;
+        const int32_t *si = TB_slice_i32(p) + row * 8;
         active = si[0]; has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
-        usecase = p.tab.slice_usecase[row];
-        priority = p.tab.slice_f64[row * 2 + 0]; traffic_tab = p.tab.slice_f64[row * 2 + 1];
+        usecase = TB_slice_usecase(p)[row];
+        priority = TB_slice_f64(p)[row * 2 + 0]; traffic_tab = TB_slice_f64(p)[row * 2 + 1];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            pm[k] = p.tab.param_i32[(row * 3 + k) * 2 + 0];
-            po[k] = p.tab.param_i32[(row * 3 + k) * 2 + 1];
-            pv[k] = p.tab.param_f64[row * 3 + k];
+            pm[k] = TB_param_i32(p)[(row * 3 + k) * 2 + 0];
+            po[k] = TB_param_i32(p)[(row * 3 + k) * 2 + 1];
+            pv[k] = TB_param_f64(p)[row * 3 + k];
         }
     }
     // ---- the UE of this slot ----------------------------------------------------------------------
     double vals[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (have) {
         const size_t su = (size_t)e * U + ue;
-        const int total = p.st.queue_pkts[su];
-        const long long sum_age = p.st.queue_age_sum[su];
-        const double sem = p.st.se_mean[su];
-        const double sent = (double)p.st.pkt_effective_thr[su], thr = (double)p.st.pkt_throughputs[su];
+        const int total = ST_queue_pkts(p)[su];
+        const long long sum_age = ST_queue_age_sum(p)[su];
+        const double sem = ST_se_mean(p)[su];
+        const double sent = (double)ST_pkt_effective_thr(p)[su], thr = (double)ST_pkt_throughputs(p)[su];
         // the heads' window: deque entry i is TTI i/2; view_len = min(2*hlen, D)
         const int vlen = 2 * hlen < D ? 2 * hlen : D;
         double sw = 0.0, dw = 0.0;
         for (int j = 0; 2 * j < vlen; j++) {
             int idx = npush - 1 - j; idx += idx < 0 ? D : 0;
             const double mult = 2 * j + 1 < vlen ? 2.0 : 1.0;
-            sw += mult * (double)p.st.ring_sent[((size_t)e * D + idx) * U + ue];
-            dw += mult * (double)p.st.ring_drop[((size_t)e * D + idx) * U + ue];
+            sw += mult * (double)ST_ring_sent(p)[((size_t)e * D + idx) * U + ue];
+            dw += mult * (double)ST_ring_drop(p)[((size_t)e * D + idx) * U + ue];
         }
         const double occ = (double)total / (double)mp;
         const double lat = total > 0 ? (double)sum_age / (double)total : 0.0;
@@ -1188,15 +1251,15 @@ __global__ void __launch_bounds__(CORE_NT) ranenv_head_kernel(const KP p)
             const int nu = sh.nues[sl];
             if (nu == 0) continue;                                               // sched_twc.py:364-365
             const size_t row = (size_t)sc * S + sl;
-            const double w = p.tab.slice_f64[row * 2 + 0] != 0.0 ? 2.0 : 1.0;    // :382-391
+            const double w = TB_slice_f64(p)[row * 2 + 0] != 0.0 ? 2.0 : 1.0;    // :382-391
             for (int k = 0; k < 3; k++) {
                 const double v = sh.sv[sl][k];
                 if (d_isclose(v, -2.0) || !(v < 0.0)) continue;                  // :376-378, :395-399
                 terms[q] = v; nw[q] = w; q++;
             }
-            const int32_t *si = p.tab.slice_i32 + row * 8;
+            const int32_t *si = TB_slice_i32(p) + row * 8;
             if (si[0] != 0) {                                                    // sched_colran.py:372-419
-                const int uc = p.tab.slice_usecase[row];
+                const int uc = TB_slice_usecase(p)[row];
                 const double pkt = (double)si[5];
                 if (uc & 1) r_col += ((sh.thr_raw[sl] * pkt) / 1e6) / 200.0;
                 if (uc & 2) r_col -= ((sh.occ_m[sl] * (double)si[3]) * pkt / 1e6) / 2000.0;
@@ -1474,28 +1537,17 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.norm_traffic = cfg->norm_traffic; kp.norm_ues = cfg->norm_ues; kp.norm_se = cfg->norm_se;
     int rc = RANENV_OK;
 #define ALLOC(field, count) if (rc == RANENV_OK) rc = dev_alloc(h, &field, (count))
+    const size_t NSL = (size_t)S * GRP;
+    kp.BU = (long long)(B * U); kp.NSU = (long long)(NS * U); kp.NSL = (long long)(NS * NSL);
     ALLOC(kp.tab.slice_i32, NS * S * 8); ALLOC(kp.tab.slice_f64, NS * S * 2);
     ALLOC(kp.tab.param_i32, NS * S * 6); ALLOC(kp.tab.param_f64, NS * S * 3);
-    ALLOC(kp.tab.slice_ues, NS * S * Us);
-    ALLOC(kp.tab.ue_slice, NS * U); ALLOC(kp.tab.ue_pos, NS * U); ALLOC(kp.tab.ue_pkt_size, NS * U);
-    ALLOC(kp.tab.ue_max_pkts, NS * U); ALLOC(kp.tab.ue_max_age, NS * U);
-    ALLOC(kp.st.queue_pkts, B * U); ALLOC(kp.st.queue_age_sum, B * U); ALLOC(kp.st.front, B * U);
-    ALLOC(kp.st.front_rem, B * U); ALLOC(kp.st.fifo, B * U); ALLOC(kp.st.win_sent, B * U); ALLOC(kp.st.win_dropped, B * U);
-    ALLOC(kp.st.se_mean, B * U);
+    ALLOC(kp.tab.slice_ues, NS * S * Us); ALLOC(kp.tab.slice_usecase, NS * S);
+    ALLOC(kp.tab.ue, 5 * NS * U); ALLOC(kp.tab.slot, 3 * NS * NSL);
+    ALLOC(kp.st.u4, (size_t)N_U4 * B * U); ALLOC(kp.st.u8, (size_t)N_U8 * B * U); ALLOC(kp.st.b4, (size_t)N_B4 * B);
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
-    ALLOC(kp.st.hist_len, B); ALLOC(kp.st.n_push, B); ALLOC(kp.st.step_no, B);
-    ALLOC(kp.st.se_pos, B); ALLOC(kp.st.trf_pos, B);
-    ALLOC(kp.st.pkt_incoming, B * U); ALLOC(kp.st.pkt_throughputs, B * U); ALLOC(kp.st.pkt_effective_thr, B * U);
-    ALLOC(kp.st.dropped_pkts, B * U); ALLOC(kp.st.rb_start, B * U); ALLOC(kp.st.rb_count, B * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
-    ALLOC(kp.st.alloc_gen, B); ALLOC(kp.st.next_rb_start, B * U); ALLOC(kp.st.next_rb_count, B * U); ALLOC(kp.st.next_scores, B * S);
-    {
-        const size_t NSL = (size_t)S * GRP;
-        ALLOC(kp.tab.slot_ue, NS * NSL); ALLOC(kp.tab.slot_mp, NS * NSL); ALLOC(kp.tab.slot_pk, NS * NSL);
-        ALLOC(kp.tab.slice_usecase, NS * S);
-    }
+    ALLOC(kp.st.next_scores, B * S);
     ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B);
-    ALLOC(kp.st.episode_no, B); ALLOC(kp.st.reset_count, B);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
@@ -1582,20 +1634,21 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
             }
     const size_t f = (size_t)first;
     const Tables &d = h->kp.tab;
+    const KP &k = h->kp;
 #define PUT(dst, src, elems, type) HIP_TRY(h, hipMemcpyAsync((dst), (src), (elems) * sizeof(type), hipMemcpyHostToDevice, stream))
     PUT(d.slice_i32 + f * S * 8, si.data(), n * S * 8, int32_t);
     PUT(d.slice_f64 + f * S * 2, sf.data(), n * S * 2, double);
     PUT(d.param_i32 + f * S * 6, pi.data(), n * S * 6, int32_t);
     PUT(d.param_f64 + f * S * 3, pf.data(), n * S * 3, double);
     PUT(d.slice_ues + f * S * Us, t->slice_ues, n * S * Us, int32_t);
-    PUT(d.ue_slice + f * U, t->ue_slice, n * U, int32_t);
-    PUT(d.ue_pos + f * U, t->ue_pos, n * U, int32_t);
-    PUT(d.ue_pkt_size + f * U, t->ue_pkt_size, n * U, int32_t);
-    PUT(d.ue_max_pkts + f * U, t->ue_max_pkts, n * U, int32_t);
-    PUT(d.ue_max_age + f * U, t->ue_max_age, n * U, int32_t);
-    PUT(d.slot_ue + f * NSL, sue.data(), n * NSL, int32_t);
-    PUT(d.slot_mp + f * NSL, smp.data(), n * NSL, int32_t);
-    PUT(d.slot_pk + f * NSL, spk.data(), n * NSL, int32_t);
+    PUT(TB_ue_slice(k) + f * U, t->ue_slice, n * U, int32_t);
+    PUT(TB_ue_pos(k) + f * U, t->ue_pos, n * U, int32_t);
+    PUT(TB_ue_pkt_size(k) + f * U, t->ue_pkt_size, n * U, int32_t);
+    PUT(TB_ue_max_pkts(k) + f * U, t->ue_max_pkts, n * U, int32_t);
+    PUT(TB_ue_max_age(k) + f * U, t->ue_max_age, n * U, int32_t);
+    PUT(TB_slot_ue(k) + f * NSL, sue.data(), n * NSL, int32_t);
+    PUT(TB_slot_mp(k) + f * NSL, smp.data(), n * NSL, int32_t);
+    PUT(TB_slot_pk(k) + f * NSL, spk.data(), n * NSL, int32_t);
 #undef PUT
     HIP_TRY(h, hipStreamSynchronize(stream));  // staging vectors die at return
     h->have_scenarios = true; h->alloc_gen++;
@@ -1816,8 +1869,8 @@ int ranenv_set_autoreset(ranenv_handle h, int32_t enable, int32_t initial_episod
         for (int b = 0; b < h->cfg.batch; b++)
             if (host_episode_no[b] < h->ep_table_first || host_episode_no[b] >= h->ep_table_first + h->ep_table_n)
                 return fail(h, RANENV_E_INVALID, "env %d: episode number %d outside the table", b, host_episode_no[b]);
-        HIP_TRY(h, hipMemcpyAsync(h->kp.st.episode_no, host_episode_no, sizeof(int32_t) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
-        HIP_TRY(h, hipMemsetAsync(h->kp.st.reset_count, 0, sizeof(int32_t) * (size_t)h->cfg.batch, stream));
+        HIP_TRY(h, hipMemcpyAsync(ST_episode_no(h->kp), host_episode_no, sizeof(int32_t) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
+        HIP_TRY(h, hipMemsetAsync(ST_reset_count(h->kp), 0, sizeof(int32_t) * (size_t)h->cfg.batch, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));
     }
     h->ar_initial = initial_episode; h->ar_max = max_episode; h->ar_random = random_episodes ? 1 : 0; h->ar_seed = seed;
@@ -1839,7 +1892,7 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     AdvanceArgs a;
     a.done = dev_done; a.mask = h->d_ar_mask; a.episodes = h->d_episodes; a.table = h->d_ep_table;
     a.table_first = h->ep_table_first; a.table_n = h->ep_table_n;
-    a.episode_no = h->kp.st.episode_no; a.reset_count = h->kp.st.reset_count;
+    a.episode_no = ST_episode_no(h->kp); a.reset_count = ST_reset_count(h->kp);
     a.initial = h->ar_initial; a.max_ep = h->ar_max; a.random = h->ar_random; a.env_id_base = h->kp.env_id_base; a.seed = h->ar_seed;
     a.obs_inter = obs_inter; a.obs_intra = obs_intra; a.head_obs = h->kp.head_obs;
     a.term_inter = obs_inter ? term_obs_inter : nullptr; a.term_intra = obs_intra ? term_obs_intra : nullptr; a.term_head = term_obs_head;
@@ -1856,15 +1909,15 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
 int ranenv_get_views(ranenv_handle h, ranenv_views *out)
 {
     if (!h || !out) return fail(h, RANENV_E_INVALID, "null argument");
-    const State &s = h->kp.st;
-    out->pkt_incoming = s.pkt_incoming; out->pkt_throughputs = s.pkt_throughputs;
-    out->pkt_effective_thr = s.pkt_effective_thr; out->dropped_pkts = s.dropped_pkts;
-    out->queue_pkts = s.queue_pkts; out->queue_age_sum = (int64_t *)s.queue_age_sum;
-    out->rb_start = s.rb_start; out->rb_count = s.rb_count; out->se_mean = s.se_mean;
-    out->win_sent = (int64_t *)s.win_sent; out->win_dropped = (int64_t *)s.win_dropped;
-    out->step_number = s.step_no; out->hist_len = s.hist_len;
-    out->mask_inter = s.mask_inter; out->mask_intra = s.mask_intra; out->policy_scores = s.policy_scores;
-    out->episode_number = s.episode_no;
+    const KP &k = h->kp;
+    out->pkt_incoming = ST_pkt_incoming(k); out->pkt_throughputs = ST_pkt_throughputs(k);
+    out->pkt_effective_thr = ST_pkt_effective_thr(k); out->dropped_pkts = ST_dropped_pkts(k);
+    out->queue_pkts = ST_queue_pkts(k); out->queue_age_sum = ST_queue_age_sum(k);
+    out->rb_start = ST_rb_start(k); out->rb_count = ST_rb_count(k); out->se_mean = ST_se_mean(k);
+    out->win_sent = ST_win_sent(k); out->win_dropped = ST_win_dropped(k);
+    out->step_number = ST_step_no(k); out->hist_len = ST_hist_len(k);
+    out->mask_inter = ST_mask_inter(k); out->mask_intra = ST_mask_intra(k); out->policy_scores = ST_policy_scores(k);
+    out->episode_number = ST_episode_no(k);
     out->episodes = reinterpret_cast<int32_t *>(h->d_episodes);
     return RANENV_OK;
 }
@@ -1886,7 +1939,7 @@ int ranenv_set_slice_usecase(ranenv_handle h, int32_t first, int32_t count, cons
     for (size_t i = 0; i < n; i++) if (usecase[i] < 0 || usecase[i] > 3) return fail(h, RANENV_E_INVALID, "use-case bits must be in [0,3]");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
-    HIP_TRY(h, hipMemcpyAsync(h->kp.tab.slice_usecase + (size_t)first * h->cfg.n_slices, usecase, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(h, hipMemcpyAsync(TB_slice_usecase(h->kp) + (size_t)first * h->cfg.n_slices, usecase, n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
     return RANENV_OK;
 }
