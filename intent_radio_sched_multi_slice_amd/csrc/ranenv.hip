@@ -277,8 +277,11 @@ DEVFN RowPlan make_row_plan(int n)
 #ifndef RANENV_LATE_DEFAULT
 #define RANENV_LATE_DEFAULT 1
 #endif
-constexpr int SE_NQ = RANENV_SE_DEPTH;   // 8-row groups in flight per lane
+#ifndef RANENV_SE_DEPTH_SMALL
+#define RANENV_SE_DEPTH_SMALL 4   /* the same for batches that do not fill the CUs anyway (step kernel built for 4 waves per SIMD) */
+#endif
 
+template <int SE_NQ>              // 8-row groups in flight per lane
 struct SeStream {
     float q[SE_NQ][8];
     __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
@@ -312,8 +315,8 @@ struct SeStream {
 // `after_issue` runs once, before the last turn of the queue (no load is requested in that turn): what the caller
 // loads there completes behind the tile (loads retire in order) while the last groups are being summed, and needs
 // no register during the rest of the stream.
-template <typename InFn, typename Hook>
-DEVFN void row_sums(SeStream &st, int R, InFn in, double &full, double &part, Hook after_issue)
+template <int SE_NQ, typename InFn, typename Hook>
+DEVFN void row_sums(SeStream<SE_NQ> &st, int R, InFn in, double &full, double &part, Hook after_issue)
 {
     const RowPlan pl = make_row_plan(R);
     const int tail = R & 7, G = R >> 3;
@@ -636,22 +639,9 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     rb_count = have ? count : 0;
 }
 
-#ifndef RANENV_WAVES_PER_EU   /* waves per SIMD the step kernel is compiled for: 5 = 96 VGPRs, 10 workgroups of 2 waves per CU
-                                 (4 = 128 VGPRs, 8 workgroups; 0 = whatever the compiler takes) */
-#define RANENV_WAVES_PER_EU 5
-#endif
-#if RANENV_WAVES_PER_EU > 0
-#if RANENV_WAVES_PER_EU > 0
-#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
-#else
-#define RANENV_CORE_ATTR
-#endif
-#else
-#define RANENV_CORE_ATTR
-#endif
-
-template <int MODE>
-__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
+// The kernel body, instantiated twice (see the two kernels behind it): NQ = groups of 8 SE loads in flight per lane.
+template <int MODE, int NQ>
+DEVFN void step_body(const KP &p)
 {
     __shared__ SharedCore sh;
     auto &xr = sh.xr;
@@ -736,7 +726,7 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     }
     const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
-    SeStream se1;
+    SeStream<NQ> se1;
     se1.init(tile, U, u, R);                       // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // zero the per-slice rows, park the tables
@@ -1085,6 +1075,26 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
     RANENV_STAMP(8);
 }
 
+// Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
+// 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 8 SE loads in flight per lane -- occupancy hides more latency
+// than a deeper queue (measured, profiles/r02_ab_log.txt).  A small batch is resident at once whatever the register
+// count, so it takes the build with 128 VGPRs and 32 loads in flight.
+#ifndef RANENV_WAVES_PER_EU
+#define RANENV_WAVES_PER_EU 5      /* experiment knob: waves per SIMD of the lean build (0 = compiler's choice) */
+#endif
+#if RANENV_WAVES_PER_EU > 0
+#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
+#else
+#define RANENV_CORE_ATTR
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p) { step_body<MODE, RANENV_SE_DEPTH>(p); }
+template <int MODE>
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
+{
+    step_body<MODE, RANENV_SE_DEPTH_SMALL>(p);
+}
+
 // =============================================================================================
 // Alternative heads: the observation of SchedTWC / SchedColORAN (agents/sched_twc.py:165-346:
 // 3 requirements + 7 slice means per slice, slices in index order, metric-major) and their rewards
@@ -1361,6 +1371,7 @@ struct ranenv {
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
+    bool small_batch = false;                   // at most 8 workgroups per CU: the 128-VGPR build with the deeper SE queue
     // ranenv_profile_begin / _end: HIP events around every kernel of every step, on the caller's stream
     bool prof_on = false;
     int prof_n = 0;                             // steps recorded
@@ -1465,7 +1476,8 @@ hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream)
     hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;
     const bool head = kp.head_obs || kp.head_reward;
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
+    if (h->small_batch) hipLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
+    else hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (head) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
     if (ev) (void)hipEventRecord(ev[2], stream);
@@ -1556,6 +1568,10 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     h->nslot = (S * GRP + WAVE - 1) / WAVE * WAVE;      // head kernel: one lane per slot
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->small_batch = (long long)cfg->batch <= 8ll * prop.multiProcessorCount;
+        if (const char *sv = getenv("RANENV_SMALL_BATCH")) h->small_batch = atoi(sv) != 0;   // experiment knob
         e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP>));
         if (e != hipSuccess) {
             ranenv_destroy(h);

@@ -12,6 +12,7 @@ run() {  # name timeout cmd...
   return $rc
 }
 run pytest 900 python -m pytest tests -q -m gpu --maxfail=${MAXFAIL:-6}
+RANENV_SMALL_BATCH=0 run pytest_lean 900 python -m pytest tests -q -m gpu --maxfail=${MAXFAIL:-6}
 for lm in ${LATE_MODES:-}; do RANENV_LATE=$lm run pytest_late$lm 900 python -m pytest tests -x -q -m gpu; done
 if [ "$#" -gt 0 ]; then run ab 600 python tools/abprobe.py "$@"; fi
 if [ -n "${STAMPS:-}" ] && [ -f tools/variants/stamps.so ]; then RANENV_LIB=$PWD/tools/variants/stamps.so run stamps 300 python tools/stamps.py; fi
