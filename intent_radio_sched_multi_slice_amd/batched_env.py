@@ -50,7 +50,10 @@ class BatchedRanEnv:
                  max_ues_slice: Optional[int] = None, n_scenarios: int = 1, bandwidth_hz: float = 100e6,
                  max_steps: int = 1000, hist_depth: int = 10, max_age_cap: int = MAX_AGE_CAP_DEFAULT,
                  overfulfill: float = 0.2, norm_traffic: float = 120.0, norm_ues: float = 5.0,
-                 norm_se: float = 40.0, device: Optional[torch.device] = None, flags: int = 0):
+                 norm_se: float = 40.0, device: Optional[torch.device] = None, flags: int = 0,
+                 strict_inputs: bool = False):
+        """``strict_inputs``: refuse per-step inputs that are not already contiguous tensors of the right dtype on
+        the env's GPU, instead of converting them (a conversion is a hidden host-to-device copy every TTI)."""
         if not torch.cuda.is_available():
             raise RanEnvError("BatchedRanEnv needs a ROCm GPU (there is no CPU fallback)")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -65,6 +68,7 @@ class BatchedRanEnv:
         self.max_steps, self.hist_depth, self.max_age_cap = int(max_steps), int(hist_depth), int(max_age_cap)
         self.bandwidth_hz = float(bandwidth_hz)
         self.n_scenarios = int(n_scenarios)
+        self.strict_inputs = bool(strict_inputs)
         self._lib = _lib.load()
         cfg = _lib.Config(_lib.ABI_VERSION, dev_index, self.B, self.S, self.U, self.R, self.G, self.Us,
                           self.hist_depth, self.max_age_cap, self.max_steps, self.n_scenarios, int(flags), 0,
@@ -115,6 +119,9 @@ class BatchedRanEnv:
     def _dev(self, x, dtype, shape, name):
         if x is None:
             return None
+        if self.strict_inputs and not (isinstance(x, torch.Tensor) and x.device == self.device and x.dtype == dtype
+                                       and x.is_contiguous()):
+            raise RanEnvError(f"{name}: strict_inputs needs a contiguous {dtype} tensor on {self.device}")
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.array(x, copy=True))
         t = t.to(device=self.device, dtype=dtype).contiguous()
         if tuple(t.shape) != tuple(shape):

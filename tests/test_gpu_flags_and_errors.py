@@ -146,6 +146,12 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(RanEnvError, match="expected shape"):
         env.step(np.zeros((2, 4)), np.zeros((2, 3), dtype=np.uint8))
     env.step(np.zeros((2, 3)), np.zeros((2, 3), dtype=np.uint8))     # and a good call still works
+    # strict inputs: no hidden per-step conversions
+    env.strict_inputs = True
+    with pytest.raises(RanEnvError, match="strict_inputs"):
+        env.step(np.zeros((2, 3)), np.zeros((2, 3), dtype=np.uint8))
+    env.step(torch.zeros((2, 3), dtype=torch.float64, device=env.device), torch.zeros((2, 3), dtype=torch.uint8, device=env.device))
+    env.strict_inputs = False
     # episode advance / traffic generator misuse
     with pytest.raises(RanEnvError, match="no episode table"):
         env.enable_autoreset(0, 2)

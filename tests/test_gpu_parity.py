@@ -204,7 +204,8 @@ def test_batch_vs_oracle(policy, intra, size):
 def test_shapes_vs_oracle(shape, variant):
     """Other sizes than the BASELINE ones: every numpy pairwise-sum shape of the SE row reduction,
     a partial last wave of UEs, a full 16 x 16 slot grid; with the caller's scores / schedulers
-    (alloc kernel every TTI) and with MAPF + PF on the device (allocation made by the post kernel)."""
+    (allocation at the head of every step) and with MAPF + PF on the device (allocation at the head of the step or,
+    for a hashed half of the envs, at the tail of the step before)."""
     _need_gpu()
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     from oracle import pyoracle
@@ -252,8 +253,8 @@ def test_shapes_vs_oracle(shape, variant):
 
 
 def test_policy_switching_vs_oracle():
-    """The allocation of a TTI is made either by the alloc kernel (caller's scores, or no stored
-    allocation) or by the post kernel of the TTI before (device policy).  Walk through every
+    """The allocation of a TTI is made either at the head of its own step (caller's scores, or no valid stored
+    allocation) or at the tail of the step before (device policy, half of the envs).  Walk through every
     hand-over: external -> MARR+RR -> MAPF+PF (set_policy in between) -> external -> dense -> MAPF+PF
     -> masked reset -> MT."""
     _need_gpu()
