@@ -57,9 +57,10 @@ def cpu_baseline(wl, sample_envs: int, sample_steps: int):
         e.set_scenario(wl.tables, int(wl.scenario[b]))
         oenvs.append(e)
     L = wl.trace_len
+    W = min(L, 64)              # the timing sample replays a window of W tiles per env (host memory: n * W * 54 KB)
     eps = env.episodes
     # tiles the sample touches, transposed to the oracle's UE-major layout
-    tile_idx = np.stack([eps["se_base"][:n] + (eps["se_offset"][:n] + t) % L for t in range(sample_steps)])
+    tile_idx = np.stack([eps["se_base"][:n] + (eps["se_offset"][:n] + t % W) % L for t in range(sample_steps)])
     uniq, inv = np.unique(tile_idx, return_inverse=True)
     inv = inv.reshape(tile_idx.shape)
     se_host = wl.se_pool[torch.as_tensor(uniq, device=env.device)].transpose(1, 2).contiguous().cpu().numpy()
@@ -72,7 +73,8 @@ def cpu_baseline(wl, sample_envs: int, sample_steps: int):
         pyoracle.batch_step(oenvs, wl.policy, None, intra, se_host, inv[t], trf_host[rows], cores)
     dt = time.perf_counter() - t0
     return {"value": n * sample_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {sample_steps} TTIs of the same workload, oracle/ranenv_oracle.c, OpenMP over envs, {dt:.2f} s"}
+            "sample": f"{n} envs x {sample_steps} TTIs of the same workload (each env cycling through {W} tiles of its trace), "
+                      f"oracle/ranenv_oracle.c, OpenMP over envs, {dt:.2f} s"}
 
 
 def rank_env():
@@ -145,7 +147,9 @@ def main():
                     help="BASELINE.json configs index: 1 = B1024 MARR+RR, 2 = B4096 MAPF+PF (default; 3 = the same "
                          "per GPU, i.e. what --gpus 8 runs), 4 = mult_slice_seq sweep B8192, mixed masks")
     ap.add_argument("--traces", type=int, default=200)
-    ap.add_argument("--trace-len", type=int, default=200)
+    ap.add_argument("--trace-len", type=int, default=1000,
+                    help="TTIs per channel trace (1000 = a whole episode: no env ever replays a tile; the pool is "
+                         "traces x trace_len x 54 KB = 10.8 GB)")
     ap.add_argument("--traffic", choices=("pool", "philox"), default="pool",
                     help="offered traffic: replayed Poisson pool (parity mode) or the device counter-based generator")
     ap.add_argument("--cpu-envs", type=int, default=256)
