@@ -562,46 +562,60 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     // ---- intra-slice: thread = UE; a slice's UEs exchange through its rows ---------------------------
     const int n = have ? sh.si[sl][2] : 0;
     const int n_rbs = have ? sh.rbs[sl] : 0, off = have ? sh.off[sl] : 0;
-    double avail = 0.0;                          // PF / MT path, evaluated by every slice
-    if (have) {
-        const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // common.py:573-578
-        const double cap = sem * slice_bw / (double)n;
-        const double backlog = occ * (double)mp * (double)pk;
-        avail = cap < backlog ? cap : backlog;
-        r0[pos] = avail;                         // (the occupancy row was consumed by the inter-slice part)
-    }
-    __syncthreads();
-    double num = avail;                                                            // MT: weights = avail
-    if (choice == RANENV_INTRA_PF) {                                               // :584-602
-        double max_avail = r0[0];
-#pragma unroll
-        for (int k = 1; k < 16; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
-        double snt = hm * (double)pk;
-        if (d_isclose(avail, 0.0)) snt = 1.0;
-        num = d_isclose(snt, 0.0) ? 2.0 * max_avail : avail / snt;
-    }
-    if (have) r1[pos] = num;
-    __syncthreads();
-    const double wsum = np_sum16_lds(r1, n);
-    const bool use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;       // :603-608
-    const double my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
-    if (have) r2[pos] = my_val;
-    __syncthreads();
-    unsigned gmv = 0;                            // which positions of the slice hold a non-zero value
-#pragma unroll
-    for (int k = 0; k < 16; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
-    const bool nzv = my_val != 0.0;
+    // PF / MT weights.  With round-robin fixed for every slice (MARR's and the heads' setting, a kernel argument, so
+    // uniform over the workgroup) none of this is needed -- not even its barriers.
+    const bool all_rr = p.fixed_intra == RANENV_INTRA_RR;
+    bool use_round = false, nzv = false;
+    double my_val = 0.0;
+    int prop = 0, m_v = 0;
     const unsigned below = (1u << pos) - 1u;
-    const int m_v = __popc(gmv), slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
-    if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
-    __syncthreads();
-    int prop = 0;
-    if (use_round) {
-        const double tot = np_sum16_lds(r3, m_v);
-        prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
+    if (!all_rr) {
+        double avail = 0.0;                      // evaluated by every slice (a per-slice choice may need it)
+        if (have) {
+            const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // common.py:573-578
+            const double cap = sem * slice_bw / (double)n;
+            const double backlog = occ * (double)mp * (double)pk;
+            avail = cap < backlog ? cap : backlog;
+            r0[pos] = avail;                     // (the occupancy row was consumed by the inter-slice part)
+        }
+        __syncthreads();
+        double num = avail;                                                            // MT: weights = avail
+        if (choice == RANENV_INTRA_PF) {                                               // :584-602
+            double snt = hm * (double)pk;
+            if (d_isclose(avail, 0.0)) snt = 1.0;
+            const bool starved = d_isclose(snt, 0.0);
+            double max_avail = 0.0;
+            if (__builtin_amdgcn_ballot_w64(starved) != 0) {       // the slice maximum is only read by UEs that sent nothing
+                max_avail = r0[0];
+#pragma unroll
+                for (int k = 1; k < 16; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+            }
+            num = starved ? 2.0 * max_avail : avail / snt;
+        }
+        if (have) r1[pos] = num;
+        __syncthreads();
+        const double wsum = np_sum16_lds(r1, n);
+        use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;                 // :603-608
+        my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
+        if (have) r2[pos] = my_val;
+        __syncthreads();
+        unsigned gmv = 0;                        // which positions of the slice hold a non-zero value
+#pragma unroll
+        for (int k = 0; k < 16; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
+        nzv = my_val != 0.0;
+        m_v = __popc(gmv);
+        const int slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
+        if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
+        __syncthreads();
+        if (use_round) {
+            const double tot = np_sum16_lds(r3, m_v);
+            prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
+        }
     }
-    if (have) sh.cnt[sl][pos] = prop;
-    __syncthreads();
+    if (!all_rr) {
+        if (have) sh.cnt[sl][pos] = prop;
+        __syncthreads();
+    }
     int count = 0;
     if (use_round) {
         int acc = 0;
@@ -629,7 +643,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
     }
-    __syncthreads();                                                               // every prop was read
+    if (!all_rr) __syncthreads();                                                  // every prop was read
     if (have) sh.cnt[sl][pos] = count;
     __syncthreads();
     int before = 0;                                                                // :464-478 contiguous ranges
