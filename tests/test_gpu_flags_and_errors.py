@@ -95,6 +95,26 @@ def test_no_raw_output_flag_only_skips_the_two_arrays():
     a.close(); b.close()
 
 
+def test_sync_check_flag_changes_nothing_but_the_waiting():
+    """RANENV_F_SYNC_CHECK: every launch waits for its kernels (an asynchronous fault would be reported by the call that
+    caused it); results are those of the ordinary, enqueue-only mode."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd import _lib
+    a, *_ = _setup(flags=0)
+    b, *_ = _setup(flags=_lib.F_SYNC_CHECK)
+    for env in (a, b):
+        env.set_policy(2, 1)
+        env.reset()
+    for _ in range(5):
+        oa, ra, _ = a.step()
+        ob, rb, _ = b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(oa["obs_inter"], ob["obs_inter"]) and torch.equal(ra, rb)
+    for k, v in a.views().items():
+        assert torch.equal(v, b.views()[k]), k
+    a.close(); b.close()
+
+
 def test_done_flag_and_step_counter():
     _need_gpu()
     steps = 5

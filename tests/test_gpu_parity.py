@@ -23,6 +23,15 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
+@pytest.fixture(params=["lean", "small"])
+def build(request, monkeypatch):
+    """The step kernel has two builds (96 VGPRs / 8 SE loads in flight for batches that fill the CUs, 128 VGPRs / 32 in
+    flight for small ones); ranenv_create picks by batch size.  Test batches are small, so the choice is forced here
+    (RANENV_SMALL_BATCH is read at create) and every case runs against both."""
+    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if request.param == "lean" else "1")
+    return request.param
+
+
 def _env(**kw):
     from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
     return BatchedRanEnv(**kw)
@@ -41,7 +50,7 @@ def _cmp_raw(env, b, raw, tag):
 
 
 @pytest.mark.parametrize("case", TRACE_CASES)
-def test_golden_traces(case):
+def test_golden_traces(case, build):
     """Closed-loop traces whose agent side was produced by the reference's own code."""
     _need_gpu()
     fx = load_golden(case)
@@ -106,7 +115,7 @@ def _oracle_batch(tabs, scen, S, U, R, G, Us, steps):
 
 @pytest.mark.parametrize("policy,intra", [(1, 0), (2, 1), (0, 255), (2, 2)])
 @pytest.mark.parametrize("size", ["ref", "scaled"])
-def test_batch_vs_oracle(policy, intra, size):
+def test_batch_vs_oracle(policy, intra, size, build):
     """B envs on distinct scenarios/traces from HBM pools, device policies, against the oracle."""
     _need_gpu()
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
@@ -201,7 +210,7 @@ def test_batch_vs_oracle(policy, intra, size):
     dict(S=5, U=30, R=48, G=2, Us=8, D=3),  # a 3-deep observation window: the ring wraps every three TTIs
 ])
 @pytest.mark.parametrize("variant", ["external", "device"])
-def test_shapes_vs_oracle(shape, variant):
+def test_shapes_vs_oracle(shape, variant, build):
     """Other sizes than the BASELINE ones: every numpy pairwise-sum shape of the SE row reduction,
     a partial last wave of UEs, a full 16 x 16 slot grid; with the caller's scores / schedulers
     (allocation at the head of every step) and with MAPF + PF on the device (allocation at the head of the step or,
@@ -252,7 +261,7 @@ def test_shapes_vs_oracle(shape, variant):
     env.close()
 
 
-def test_policy_switching_vs_oracle():
+def test_policy_switching_vs_oracle(build):
     """The allocation of a TTI is made either at the head of its own step (caller's scores, or no valid stored
     allocation) or at the tail of the step before (device policy, half of the envs).  Walk through every
     hand-over: external -> MARR+RR -> MAPF+PF (set_policy in between) -> external -> dense -> MAPF+PF
