@@ -6,7 +6,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one TTI of every env of the batch (device MAPF policy -> inter-slice split -> PF
-intra-slice -> UEs.step -> intent observation and reward).  Workload at N=1: BASELINE.json configs[2], the configuration the north_star's
+intra-slice -> UEs.step -> intent observation and reward).  The K timed steps are enqueued with
+``ranenv_rollout`` over 3 batch partitions (ranges of independent envs, each stepped by its own launch on its own HIP
+stream, joined with the caller's stream before the first and after the last TTI); the same K steps as one launch per
+TTI on one stream are timed right after and reported beside it (``single_stream``).  Workload at N=1: BASELINE.json configs[2], the configuration the north_star's
 throughput target is quoted on (mult_slice, 10 slices / 100 UEs / 135 RBGs, batch 4096, PF
 intra-slice + ib_sched intent reward); with N GPUs every rank steps its own 4096 envs (weak
 scaling; N=8 is configs[3], batch 32768 sharded 8x).  Inputs (scenario, SE and traffic pools)
@@ -94,22 +97,20 @@ def timed_steps(step_fn, n_steps: int, sync_fn, barrier_fn, max_over_ranks_fn):
     return max_over_ranks_fn(time.perf_counter() - t0)
 
 
-def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed, kernel_ms, traffic, metrics,
-               workload_extra=""):
-    """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region;
-    the per-kernel device durations (HIP events on the launch stream, same K steps repeated with events
-    on) are listed beside them."""
+def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed, launch_ms, n_launches, parts, traffic, metrics,
+               workload_extra="", single_stream=None):
+    """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region (the whole TTI of the
+    whole batch); the step kernel's per-launch duration (the dispatch's own timestamps, from the same K steps repeated
+    with timing on) is listed beside it -- with partitions `parts` launches of batch/parts envs overlap."""
     S, U, R = env_sizes
     total_env_steps = batch * world * args.steps
     value = total_env_steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    alg_bytes = alg_bytes_env_step * batch                       # per launch (= one TTI of one rank's batch)
+    alg_bytes = alg_bytes_env_step * batch                       # per TTI of one rank's batch
     achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9            # per-GPU GB/s on the wall clock
-    dev_ms = sum(v for k, v in kernel_ms.items() if k != "n_steps")
-    dom = max((k for k in kernel_ms if k != "n_steps"), key=lambda k: kernel_ms[k])
-    dom_bytes = alg_bytes                                       # one kernel does the whole TTI
-    dom_gbs = dom_bytes / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
-    return {
+    launch_bytes = alg_bytes / parts
+    launch_gbs = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    line = {
         "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -117,24 +118,28 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed
         "config": {"workload": f"BASELINE.json configs[{args.config}]: {label}; batch {batch} per GPU; SE replayed from "
                                f"an HBM pool of {args.traces}x{args.trace_len} float32 tiles{workload_extra}",
                    "batch_per_gpu": batch, "global_batch": batch * world, "n_slices": S, "n_ues": U,
-                   "n_rbs": R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only"},
+                   "n_rbs": R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only",
+                   "launch": (f"ranenv_rollout: the K TTIs enqueued in one call, batch stepped as {parts} partitions on {parts} "
+                              "HIP streams (one launch of the step kernel per partition and TTI)") if parts > 1 else
+                             "one launch of the step kernel per TTI on one stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "clock": "wall clock of the timed region (same as value)",
                      "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
                      "traffic_source": traffic.get("source") if traffic else None,
-                     "kernel": "one TTI = " + " + ".join(k for k in kernel_ms if k != "n_steps" and kernel_ms[k] > 0),
+                     "kernel": "ranenv_core_kernel<STEP> (one TTI = %d concurrent launch(es) of it)" % parts,
                      "algorithmic_bytes_per_env_step": alg_bytes_env_step,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "device_ms_per_step": dev_ms,
-                     "frac_device": (alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dev_ms > 0 else None,
-                     "kernels_ms": {k: v for k, v in kernel_ms.items() if k != "n_steps"},
-                     "kernels_ms_source": f"HIP events on the launch stream around each kernel, {kernel_ms.get('n_steps', 0)} "
-                                          "steps repeated right after the timed region, each step waited for (a kernel "
-                                          "timed alone, as rocprofv3 --kernel-trace times it)",
-                     "dominant_kernel": {"name": dom, "ms": kernel_ms[dom], "algorithmic_bytes": dom_bytes,
-                                         "achieved": dom_gbs, "frac": dom_gbs / HBM_PEAK_GBS}},
+                     "algorithmic_bytes_per_tti": alg_bytes,
+                     "dominant_kernel": {"name": "ranenv_core_kernel<STEP>", "ms": launch_ms, "n_launches": n_launches,
+                                         "envs_per_launch": batch / parts, "algorithmic_bytes": launch_bytes,
+                                         "achieved": launch_gbs, "frac": launch_gbs / HBM_PEAK_GBS,
+                                         "concurrent_launches": parts,
+                                         "source": "hipExtLaunchKernel start/stop events of every launch, the K steps repeated "
+                                                   "right after the timed region under the same schedule"}},
         "metrics": metrics,
     }
+    if single_stream is not None:
+        line["single_stream"] = single_stream
+    return line
 
 
 def main():
@@ -152,6 +157,8 @@ def main():
                          "traces x trace_len x 54 KB = 10.8 GB)")
     ap.add_argument("--traffic", choices=("pool", "philox"), default="pool",
                     help="offered traffic: replayed Poisson pool (parity mode) or the device counter-based generator")
+    ap.add_argument("--partitions", type=int, default=None,
+                    help="batch partitions on their own HIP streams (default: 3 when the batch fills the CUs, else 1)")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,9 +186,10 @@ def main():
                                     trace_len=args.trace_len, rank=rank, traffic=args.traffic)
     env = wl.env
     batch = env.B
+    parts = args.partitions if args.partitions is not None else (3 if batch >= 2048 else 1)
+    env.set_partitions(parts)
     env.reset()
-    for _ in range(args.warmup):
-        env.step()
+    env.rollout(max(1, args.warmup))
     gather_metrics(local_metrics(env.reward, env.views(), env.done, 1))   # warm torch's reduction kernels / RCCL
 
     def max_over_ranks(x):
@@ -192,15 +200,21 @@ def main():
         return float(t.item())
 
     barrier = dist.barrier if world > 1 else (lambda: None)
-    elapsed = timed_steps(env.step, args.steps, torch.cuda.synchronize, barrier, max_over_ranks)
+    # EXACTLY K steps: one ranenv_rollout call enqueues the K TTIs of every env
+    elapsed = timed_steps(lambda: env.rollout(args.steps), 1, torch.cuda.synchronize, barrier, max_over_ranks)
     # metrics: the only collective, once per reporting interval, outside the timed K steps
     gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, args.steps))
-    # the same K steps again with HIP events around every kernel (on the stream they are launched on)
+    # the same K steps again with the dispatch timestamps of every launch
     env.profile_begin()
-    for _ in range(args.steps):
-        env.step()
+    env.rollout(args.steps)
     kms = env.profile_end()
-    kernel_ms = {"ranenv_core_kernel<STEP>": kms["step"], "n_steps": kms["n_steps"]}
+    # ... and as one launch per TTI on one stream (what a caller that consumes every TTI's outputs gets)
+    single = None
+    if parts > 1:
+        env.set_partitions(1)
+        el1 = timed_steps(env.step, args.steps, torch.cuda.synchronize, barrier, max_over_ranks)
+        single = {"value": batch * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
+                  "launch": "one launch of the step kernel per TTI on one stream (env.step() in a loop)"}
 
     if rank == 0:
         traffic = None
@@ -215,9 +229,10 @@ def main():
             except Exception:
                 traffic = None
         line = build_line(args, world, batch, label, (env.S, env.U, env.R), env.algorithmic_bytes_per_env_step(),
-                          elapsed, kernel_ms, traffic, summarize(gathered.cpu()),
+                          elapsed, kms["step"], kms["n_launches"], parts, traffic, summarize(gathered.cpu()),
                           workload_extra=(", Poisson traffic pool" if args.traffic == "pool"
-                                          else ", Poisson traffic drawn on the device (Philox4x32-10)"))
+                                          else ", Poisson traffic drawn on the device (Philox4x32-10)"),
+                          single_stream=single)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_envs, args.cpu_steps)
         print(json.dumps(line), flush=True)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 3
+#define RANENV_ABI_VERSION 4
 
 enum {
     RANENV_OK = 0,
@@ -204,12 +204,26 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
 
-/* Per-kernel timing of ordinary steps: between ranenv_profile_begin and ranenv_profile_end every reset / step /
- * step_dense call records HIP events around each of its kernels on the stream it launches on and waits for them
- * (a profiled step runs alone on the device, as under rocprofv3).  ranenv_profile_end returns the average duration
- * in ms of {step kernel, head kernel} over the n_steps profiled calls. */
+/* Per-launch timing: between ranenv_profile_begin and ranenv_profile_end every launch of the step kernel carries its
+ * dispatch's own start / stop timestamps (hipExtLaunchKernel events, valid with further launches queued behind it).
+ * ranenv_profile_end waits for the device and returns the average duration in ms over n_launches launches (with
+ * partitions: one launch per partition and TTI). */
 int ranenv_profile_begin(ranenv_handle h);
-int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps);
+int ranenv_profile_end(ranenv_handle h, double *avg_ms, int32_t *n_launches);
+
+/* Batch partitions: envs are independent, so the batch can be stepped as n_parts contiguous ranges, each by its own
+ * launch on its own (handle-owned) HIP stream.  A launch has a ramp and a tail during which CUs idle; with partitions
+ * one range's ramp and tail run under the other ranges' steady state.  reset / step / step_dense stay ordered with the
+ * caller's stream (they wait for what it holds and it waits for them), so nothing changes for a caller that consumes
+ * every TTI's outputs.  n_parts = 1 (default) launches on the caller's stream itself. */
+int ranenv_set_partitions(ranenv_handle h, int32_t n_parts);
+
+/* n_steps TTIs under the device policy (the reference's MARR / MAPF evaluation loop, simu.py:555-566, where no learner
+ * sits between two TTIs), enqueued in one call: per TTI the same launches as ranenv_step, but the caller's stream is
+ * joined only before the first and after the last TTI, so that with partitions range k's TTI t+1 follows its own
+ * TTI t directly.  The outputs hold the last TTI's values.  Needs a device policy and bound pools / generator. */
+int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *dev_obs_inter, float *dev_obs_intra,
+                   double *dev_reward, uint8_t *dev_done, void *stream);
 
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 

@@ -403,15 +403,33 @@ class BatchedRanEnv:
         }
 
     def profile_begin(self):
-        """Time every kernel of the following reset/step calls with HIP events (each profiled call waits for its kernels)."""
+        """Time every launch of the step kernel from here on (the dispatch's own start / stop timestamps)."""
         self._check(self._lib.ranenv_profile_begin(self._h), "ranenv_profile_begin")
 
     def profile_end(self) -> Dict[str, float]:
-        """Average kernel durations in ms over the profiled calls: {'step','head','n_steps'}."""
-        ms = (C.c_double * 2)()
-        n = C.c_int32()
-        self._check(self._lib.ranenv_profile_end(self._h, ms, C.byref(n)), "ranenv_profile_end")
-        return {"step": ms[0], "head": ms[1], "n_steps": n.value}
+        """Average duration in ms of the step-kernel launches since profile_begin: {'step', 'n_launches'}."""
+        ms, n = C.c_double(), C.c_int32()
+        self._check(self._lib.ranenv_profile_end(self._h, C.byref(ms), C.byref(n)), "ranenv_profile_end")
+        return {"step": ms.value, "n_launches": n.value}
+
+    def set_partitions(self, n_parts: int):
+        """Step the batch as ``n_parts`` contiguous ranges of envs, each by its own launch on its own stream
+        (ranenv_set_partitions): one range's launch ramp and tail then run under the others' steady state."""
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_partitions(self._h, int(n_parts)), "ranenv_set_partitions")
+        self.n_parts = int(n_parts)
+
+    def rollout(self, n_steps: int):
+        """``n_steps`` TTIs under the device policy enqueued in one call (MARR / MAPF evaluation runs): the launches of
+        ``n_steps`` calls of ``step()``, joined with the current stream only before the first and after the last TTI.
+        Returns the last TTI's (obs, reward, done)."""
+        if self._recorder is not None or self._autoreset:
+            raise RanEnvError("rollout() does not return between TTIs: the recorder and auto-reset need step()")
+        st = self._lib.ranenv_rollout(self._h, int(n_steps), *self._p_out,
+                                      C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if st != 0:
+            self._check(st, "ranenv_rollout")
+        return self._obs(), self.reward, self.done
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

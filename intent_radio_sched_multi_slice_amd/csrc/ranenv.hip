@@ -28,6 +28,7 @@
 //   agents/marr.py:40-47, agents/mapf.py:41-111 baseline policies
 //   sixg_radio_mgmt UEs/Buffer (un-vendored): normative restatement in oracle/ranenv_oracle.c
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -1386,11 +1387,18 @@ struct ranenv {
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
     bool small_batch = false;                   // at most 8 workgroups per CU: the 128-VGPR build with the deeper SE queue
-    // ranenv_profile_begin / _end: HIP events around every kernel of every step, on the caller's stream
+    // ranenv_profile_begin / _end: the dispatch's own start / stop timestamps of every step-kernel launch
+    // (hipExtLaunchKernel's events: valid with further launches queued behind, unlike events recorded between launches)
     bool prof_on = false;
-    int prof_n = 0;                             // steps recorded
-    double prof_ms[2] = {0.0, 0.0};             // summed durations: step kernel, head kernel
-    hipEvent_t prof_ev[3] = {};                 // before the step kernel, after it, after the head kernel
+    std::vector<hipEvent_t> prof_ev;            // pairs (start, stop), one per launch
+    size_t prof_used = 0;
+    // batch partitions (ranenv_set_partitions): envs [part_lo[k], part_lo[k+1]) are stepped by their own launch on
+    // their own stream, so that one partition's ramp and tail run under the other partitions' steady state
+    int n_parts = 1;
+    std::vector<hipStream_t> part_stream;
+    std::vector<hipEvent_t> part_done;
+    std::vector<int> part_lo;
+    hipEvent_t ev_in = nullptr;
     std::string err;
 };
 
@@ -1478,37 +1486,73 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
     return RANENV_OK;
 }
 
-// One TTI of the whole batch on the caller's stream: the step kernel (+ the head kernel when bound).
+// One launch of the step kernel for envs [e0, e0 + n) on `stream` (+ the head kernel when bound).
 template <int MODE>
-hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream)
+hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t stream)
 {
-    kp.e0 = 0; kp.alloc_gen = h->alloc_gen;
-    const dim3 grid((unsigned)kp.B);
-    // per-kernel timing (ranenv_profile_begin): events on the launch stream around each kernel.  The call waits for
-    // its kernels: with further launches queued behind, the runtime's event timestamps bracket the gap between
-    // kernels rather than the kernel (measured), so a profiled step is timed alone, as rocprofv3 times it.
-    hipEvent_t *ev = h->prof_on ? h->prof_ev : nullptr;
-    const bool head = kp.head_obs || kp.head_reward;
-    if (ev) (void)hipEventRecord(ev[0], stream);
-    if (h->small_batch) hipLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
-    else hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, dim3((unsigned)h->nt), 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    if (head) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
-    if (ev) (void)hipEventRecord(ev[2], stream);
-    const hipError_t le = hipGetLastError();
-    if (le != hipSuccess) return le;
-    if (ev) {
-        hipError_t pe = hipEventSynchronize(ev[2]);
-        for (int k = 0; k < 2 && pe == hipSuccess; k++) {
-            float ms = 0.0f;
-            pe = hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
-            h->prof_ms[k] += (double)ms;
+    kp.e0 = e0;
+    const dim3 grid((unsigned)n), block((unsigned)h->nt);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (h->prof_on) {                              // two more events from the pool
+        while (h->prof_ev.size() < h->prof_used + 2) {
+            hipEvent_t e = nullptr;
+            const hipError_t ce = hipEventCreate(&e);
+            if (ce != hipSuccess) return ce;
+            h->prof_ev.push_back(e);
         }
-        if (pe != hipSuccess) return pe;
-        h->prof_n++;
+        ev0 = h->prof_ev[h->prof_used]; ev1 = h->prof_ev[h->prof_used + 1];
+        h->prof_used += 2;
     }
-    // RANENV_F_SYNC_CHECK: surface asynchronous kernel faults at the call that caused them
-    if (h->cfg.flags & RANENV_F_SYNC_CHECK) return hipStreamSynchronize(stream);
+    if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
+        if (h->small_batch) hipExtLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
+        else hipExtLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
+    } else {
+        if (h->small_batch) hipLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, block, 0, stream, kp);
+        else hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, block, 0, stream, kp);
+    }
+    if (kp.head_obs || kp.head_reward) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
+    return hipGetLastError();
+}
+
+// One TTI of the whole batch.  Without partitions: one launch on the caller's stream.  With partitions: one launch
+// per partition on the partition's own stream; `join_in` orders them behind what the caller's stream holds so far
+// (inputs), `join_out` orders the caller's stream behind them (outputs).  ranenv_rollout enqueues n TTIs with a join
+// only before the first and after the last: partition k's TTI t+1 then follows its own TTI t directly, whatever the
+// other partitions are doing -- envs are independent, nothing else orders them.
+template <int MODE>
+hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = true, bool join_out = true)
+{
+    kp.alloc_gen = h->alloc_gen;
+    hipError_t le = hipSuccess;
+    if (h->n_parts <= 1) {
+        le = launch_range<MODE>(h, kp, 0, kp.B, stream);
+        if (le != hipSuccess) return le;
+        // RANENV_F_SYNC_CHECK: surface asynchronous kernel faults at the call that caused them
+        if (h->cfg.flags & RANENV_F_SYNC_CHECK) return hipStreamSynchronize(stream);
+        return hipSuccess;
+    }
+    if (join_in) {
+        le = hipEventRecord(h->ev_in, stream);
+        if (le != hipSuccess) return le;
+    }
+    // partition 0 runs on the caller's stream itself (a process has few hardware queues -- 4 by default -- and streams
+    // beyond them share one, i.e. run one after the other), partitions 1.. on the handle's streams
+    for (int k = 1; k < h->n_parts; k++) {
+        hipStream_t ps = h->part_stream[k];
+        if (join_in) { le = hipStreamWaitEvent(ps, h->ev_in, 0); if (le != hipSuccess) return le; }
+        le = launch_range<MODE>(h, kp, h->part_lo[k], h->part_lo[k + 1] - h->part_lo[k], ps);
+        if (le != hipSuccess) return le;
+        if (join_out) { le = hipEventRecord(h->part_done[k], ps); if (le != hipSuccess) return le; }
+    }
+    le = launch_range<MODE>(h, kp, h->part_lo[0], h->part_lo[1] - h->part_lo[0], stream);
+    if (le != hipSuccess) return le;
+    if (join_out)
+        for (int k = 1; k < h->n_parts; k++) { le = hipStreamWaitEvent(stream, h->part_done[k], 0); if (le != hipSuccess) return le; }
+    if (h->cfg.flags & RANENV_F_SYNC_CHECK) {
+        le = hipStreamSynchronize(stream);
+        for (int k = 1; k < h->n_parts && le == hipSuccess; k++) le = hipStreamSynchronize(h->part_stream[k]);
+        return le;
+    }
     return hipSuccess;
 }
 
@@ -1602,6 +1646,9 @@ int ranenv_destroy(ranenv_handle h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->part_done) if (e) (void)hipEventDestroy(e);
+    for (auto &st : h->part_stream) if (st) (void)hipStreamDestroy(st);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
     return RANENV_OK;
@@ -1802,18 +1849,64 @@ int ranenv_profile_begin(ranenv_handle h)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    for (auto &e : h->prof_ev) if (!e) HIP_TRY(h, hipEventCreate(&e));
-    h->prof_n = 0; h->prof_ms[0] = h->prof_ms[1] = 0.0; h->prof_on = true;
+    h->prof_used = 0; h->prof_on = true;
     return RANENV_OK;
 }
 
-int ranenv_profile_end(ranenv_handle h, double *avg_ms2, int32_t *n_steps)
+int ranenv_profile_end(ranenv_handle h, double *avg_ms, int32_t *n_launches)
 {
-    if (!h || !avg_ms2 || !n_steps) return fail(h, RANENV_E_INVALID, "null argument");
+    if (!h || !avg_ms || !n_launches) return fail(h, RANENV_E_INVALID, "null argument");
     if (!h->prof_on) return fail(h, RANENV_E_STATE, "ranenv_profile_begin was not called");
     h->prof_on = false;
-    for (int k = 0; k < 2; k++) avg_ms2[k] = h->prof_n > 0 ? h->prof_ms[k] / (double)h->prof_n : 0.0;
-    *n_steps = h->prof_n;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    double acc = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+        acc += (double)ms;
+    }
+    *n_launches = (int32_t)(h->prof_used / 2);
+    *avg_ms = h->prof_used ? acc / (double)(h->prof_used / 2) : 0.0;
+    return RANENV_OK;
+}
+
+int ranenv_set_partitions(ranenv_handle h, int32_t n_parts)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (n_parts < 1 || n_parts > 16 || n_parts > h->cfg.batch) return fail(h, RANENV_E_INVALID, "n_parts must be in [1, min(16, batch)]");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    while ((int)h->part_stream.size() < n_parts) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        HIP_TRY(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->part_stream.push_back(st);
+        HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->part_done.push_back(ev);
+    }
+    if (!h->ev_in) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+    h->part_lo.assign((size_t)n_parts + 1, 0);
+    const int B = h->cfg.batch, base = B / n_parts, rem = B % n_parts;
+    for (int k = 0; k < n_parts; k++) h->part_lo[k + 1] = h->part_lo[k] + base + (k < rem ? 1 : 0);
+    h->n_parts = n_parts;
+    return RANENV_OK;
+}
+
+int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *obs_intra, double *reward, uint8_t *done, void *stream_)
+{
+    int rc = check_ready(h, nullptr, nullptr, true);
+    if (rc != RANENV_OK) return rc;
+    if (n_steps < 1) return fail(h, RANENV_E_INVALID, "n_steps must be >= 1");
+    if (h->kp.policy == RANENV_POLICY_EXTERNAL) return fail(h, RANENV_E_STATE, "a rollout needs a device policy (ranenv_set_policy MARR / MAPF)");
+    if (!h->kp.se_pool || (!h->kp.trf_pool && !h->kp.trf_gen)) return fail(h, RANENV_E_STATE, "a rollout replays the bound SE pool and traffic pool / generator");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    KP kp = h->kp;
+    kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
+    kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
+    for (int i = 0; i < n_steps; i++) {
+        const hipError_t e = launch<MODE_STEP>(h, kp, (hipStream_t)stream_, i == 0, i == n_steps - 1);
+        if (e != hipSuccess) return fail(h, RANENV_E_HIP, "rollout launch %d: %s", i, hipGetErrorString(e));
+    }
     return RANENV_OK;
 }
 

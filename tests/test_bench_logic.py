@@ -41,8 +41,7 @@ assert env.n == K
 gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
 assert gathered.shape == (world, 8)
 args = types.SimpleNamespace(steps=K, warmup=2, config=2, traces=4, trace_len=5)
-line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, elapsed, {"ranenv_core_kernel<STEP>": 0.5, "n_steps": K}, None,
-                        summarize(gathered))
+line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, elapsed, 0.5, 2 * K, 2, None, summarize(gathered))
 if rank == 0:
     print("LINE " + json.dumps(line), flush=True)
 print(f"RANK {rank} elapsed {elapsed!r} lo {lo} hi {hi}", flush=True)
@@ -73,7 +72,8 @@ def test_bench_rank_logic_world_size_2_gloo(tmp_path):
     assert line["ms_per_step"] == pytest.approx(e0 / K * 1e3, rel=1e-9)
     rf = line["roofline"]
     assert rf["frac"] == pytest.approx(line["value"] / world * 1000 / 8e12, rel=1e-9)   # same clock as value, per GPU
-    assert rf["dominant_kernel"]["ms"] == 0.5 and rf["traffic"] is None
+    assert rf["dominant_kernel"]["ms"] == 0.5 and rf["traffic"] is None and rf["dominant_kernel"]["concurrent_launches"] == 2
+    assert rf["dominant_kernel"]["algorithmic_bytes"] == 1000 * B / 2 and "partitions" in line["config"]["launch"]
     m = line["metrics"]
     assert m["env_steps"] == B * K * world and m["pkts_sent"] == B * 5 * (1 + 2) and m["pkts_incoming"] == 2 * m["pkts_sent"]
     assert line["config"]["global_batch"] == B * world

@@ -113,3 +113,80 @@ def test_config1_marr_rr_vs_oracle_and_properties():
     _follow_oracle(wl, list(range(0, 1024, 64)), 24)
     _conservation(wl, 20)
     wl.env.close()
+
+
+@pytest.mark.parametrize("policy,intra,parts", [(2, 1, 1), (2, 1, 3), (1, 0, 4)])
+def test_rollout_and_partitions_equal_repeated_steps(policy, intra, parts):
+    """ranenv_rollout(n) over batch partitions = n x ranenv_step on one stream: every state array, the raw outputs and
+    the last TTI's observation / reward bit for bit (the partitions are ranges of independent envs on their own HIP
+    streams; joined steps in between must keep the order with the caller's stream)."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    outs = []
+    for mode in ("steps", "rollout"):
+        wl = make_mult_slice_workload(100, torch.device("cuda", 0), policy=policy, intra=intra, n_scenarios=8, n_traces=10, trace_len=9,
+                                      max_steps=60)
+        env = wl.env
+        if mode == "rollout":
+            env.set_partitions(parts)
+        env.reset()
+        if mode == "steps":
+            for t in range(13 + 1 + 25):
+                env.step()
+            mid = None
+        else:
+            env.rollout(13)
+            env.step()                                        # a joined step between two rollouts
+            mid = env.views()["step_number"].clone()           # read on the caller's stream: ordered behind the partitions
+            env.rollout(25)
+        v = {k: x.clone() for k, x in env.views().items()}
+        outs.append((v, env.obs_inter.clone(), env.obs_intra.clone(), env.reward.clone(), env.done.clone(), mid))
+        env.close()
+    (va, oia, oaa, ra, da, _), (vb, oib, oab, rb, db, mid) = outs
+    assert int(mid.min()) == 14 and int(mid.max()) == 14
+    for k in va:
+        assert torch.equal(va[k], vb[k]), k
+    assert torch.equal(oia, oib) and torch.equal(oaa, oab) and torch.equal(ra, rb) and torch.equal(da, db)
+
+
+def test_partitioned_steps_with_external_inputs_vs_oracle():
+    """Partitions under the ordinary step(): inputs produced on the caller's stream right before the call, outputs
+    consumed right after it; masked reset and the head kernel go through the same partitioned launch."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    from oracle import pyoracle
+    B, steps = 24, 10
+    wl = make_mult_slice_workload(B, torch.device("cuda", 0), policy=0, intra=255, n_scenarios=6, n_traces=8, trace_len=10,
+                                  n_slices=5, n_ues=25, n_rbs=135, rbs_per_rbg=5, max_ues_slice=10, max_steps=steps)
+    env, tabs = wl.env, wl.tables
+    env.set_partitions(5)
+    S, U, R = env.S, env.U, env.R
+    cfg = pyoracle.make_cfg(S, U, R, env.G, env.Us, max_steps=steps)
+    se_host = wl.se_pool.transpose(1, 2).contiguous().cpu().numpy()
+    trf_host = wl.traffic_pool.cpu().numpy().astype(np.float64)
+    eps, L = env.episodes, wl.trace_len
+    oenvs = []
+    for b in range(B):
+        o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, int(wl.scenario[b]))
+        o.reset(se_host[int(eps["se_base"][b] + eps["se_offset"][b] % L)]); oenvs.append(o)
+    env.reset()
+    g = torch.Generator(device=env.device); g.manual_seed(5)
+    for t in range(steps):
+        sc = torch.rand((B, S), generator=g, device=env.device, dtype=torch.float64) * 2 - 1     # produced on the stream
+        ic = torch.randint(0, 3, (B, S), generator=g, device=env.device, dtype=torch.uint8)
+        obs, rew, done = env.step(sc, ic)
+        r = rew.cpu().numpy(); oi = obs["obs_inter"].cpu().numpy()                                 # consumed right away
+        scn, icn = sc.cpu().numpy(), ic.cpu().numpy()
+        for b, o in enumerate(oenvs):
+            tile = int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)
+            row = int(eps["trf_base"][b] + (eps["trf_offset"][b] + t) % L)
+            o.step(scn[b], icn[b].astype(np.int32), se_host[tile], trf_host[row])
+            oo = o.obs()
+            np.testing.assert_allclose(oi[b], oo["obs_inter"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(r[b], oo["reward"], rtol=0, atol=REW_TOL)
+    assert bool(done.all())
+    mask = (np.arange(B) % 2).astype(np.uint8)
+    env.reset(env_mask=mask)
+    sn = env.views()["step_number"].cpu().numpy()
+    assert np.array_equal(sn == 0, mask == 1)
+    env.close()

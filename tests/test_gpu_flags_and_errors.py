@@ -115,6 +115,33 @@ def test_sync_check_flag_changes_nothing_but_the_waiting():
     a.close(); b.close()
 
 
+def test_shorter_trace_mid_episode_cannot_read_past_the_pool():
+    """A trace position persisted under a longer trace is reduced when set_episodes installs a shorter one mid-episode
+    (no reset in between): the next step reads tile 0 of the new trace -- inside the bound pool -- not position 9 of a
+    4-tile trace."""
+    _need_gpu()
+    steps, B = 12, 4
+    env, tabs, scen, se_pool, trf, dims = _setup(steps=steps, B=B)
+    S, U, R, G, Us = dims
+    env.set_policy(1, 0)
+    env.reset()
+    for _ in range(9):
+        env.step()                                    # positions are now 9 in 12-tile traces
+    short = 4
+    base = (np.arange(B) * steps + steps - short).astype(np.int64)          # the LAST 4 tiles of each env's range:
+    env.set_episodes(scenario=scen, se_base=base, se_len=short,             # position 9 would lie beyond the pool for env B-1
+                     trf_base=np.arange(B) * steps, trf_len=short)
+    v = env.views()
+    q_before = v["queue_pkts"].clone()
+    env.step()
+    torch.cuda.synchronize()
+    # the step used tile base + 0: the mean SE it stored is that tile's
+    want = np.stack([se_pool[int(base[b])].astype(np.float64).mean(axis=1) for b in range(B)])
+    np.testing.assert_allclose(v["se_mean"].cpu().numpy(), want, rtol=1e-12, atol=0)
+    assert int(v["step_number"][0]) == 10 and torch.isfinite(env.reward).all()
+    env.close()
+
+
 def test_done_flag_and_step_counter():
     _need_gpu()
     steps = 5
