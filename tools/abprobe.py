@@ -16,13 +16,13 @@ for rep in range(3):
         if lib != "default":
             env["RANENV_LIB"] = os.path.abspath(lib)
         out = subprocess.run([sys.executable, "tools/benchprobe.py", config], env=env, capture_output=True, text=True)
-        m = re.search(r"step\s+([\d.]+) us\s+kernel\s+([\d.]+)", out.stdout)
+        m = re.search(r"step\s+([\d.]+) us\s+kernel\s+([\d.]+)(?:\s+rollout x\d+\s+([\d.]+))?", out.stdout)
         if not m:
             print(l, "FAILED", out.stdout[-300:], out.stderr[-600:], flush=True)
             continue
-        res[l].append(tuple(float(x) for x in m.groups()))
+        res[l].append(tuple(float(x) if x else 0.0 for x in m.groups()))
         print(l, res[l][-1], flush=True)
 for l in libs:
     a = res[l]
     if a:
-        print(f"{l:32s} step {sum(x[0] for x in a) / len(a):6.1f}  kernel {sum(x[1] for x in a) / len(a):6.1f}   (min step {min(x[0] for x in a):.1f})")
+        print(f"{l:32s} step {sum(x[0] for x in a) / len(a):6.1f}  kernel {sum(x[1] for x in a) / len(a):6.1f}  rollout {sum(x[2] for x in a) / len(a):6.1f}   (min step {min(x[0] for x in a):.1f})")

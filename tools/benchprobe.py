@@ -18,11 +18,12 @@ e0.record()
 for _ in range(K):
     env.step()
 e1.record(); torch.cuda.synchronize()
+step_us = e0.elapsed_time(e1) / K * 1e3
 env.profile_begin()
 for _ in range(100):
     env.step()
 k = env.profile_end()
-parts = int(os.environ.get("RANENV_PARTS", "1"))
+parts = int(os.environ.get("RANENV_PARTS", "3"))
 extra = ""
 if parts > 1:
     env.set_partitions(parts)
@@ -30,5 +31,5 @@ if parts > 1:
     e0.record(); env.rollout(K); e1.record(); torch.cuda.synchronize()
     r = e0.elapsed_time(e1) / K * 1e3
     env.profile_begin(); env.rollout(100); kk = env.profile_end()
-    extra = f"   rollout x{parts} parts {r:6.1f} us/TTI (launch avg {kk['step'] * 1e3:6.1f} us, {kk['n_launches']} launches)"
-print(f"{os.path.basename(os.environ.get('RANENV_LIB', 'default')):14s} cfg {config} step {e0.elapsed_time(e1) / K * 1e3 if parts <= 1 else 0:6.1f} us   kernel {k['step'] * 1e3:6.1f}{extra}", flush=True)
+    extra = f"   rollout x{parts} {r:6.1f} us/TTI (launch avg {kk['step'] * 1e3:6.1f})"
+print(f"{os.path.basename(os.environ.get('RANENV_LIB', 'default')):14s} cfg {config} step {step_us:6.1f} us   kernel {k['step'] * 1e3:6.1f}{extra}", flush=True)

@@ -24,6 +24,8 @@ python3 tools/pmc_summary.py $out/pmc_sq $out/pmc_sq2 > $out/pmc_sq_summary.txt;
 step bench_prof 400 rocprofv3 --kernel-trace --stats -d $out/prof -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline
 step bench 600 python3 bench.py
 step bench_driver 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
+step bench_single 300 python3 bench.py --partitions 1 --no-cpu-baseline
+step bench_philox 300 python3 bench.py --traffic philox --no-cpu-baseline
 step bench_cfg1 300 python3 bench.py --config 1 --no-cpu-baseline
 step bench_cfg4 300 python3 bench.py --config 4 --no-cpu-baseline
 if [ -f tools/variants/stamps.so ]; then
