@@ -158,7 +158,8 @@ def main():
     ap.add_argument("--traffic", choices=("pool", "philox"), default="pool",
                     help="offered traffic: replayed Poisson pool (parity mode) or the device counter-based generator")
     ap.add_argument("--partitions", type=int, default=None,
-                    help="batch partitions on their own HIP streams (default: 3 when the batch fills the CUs, else 1)")
+                    help="batch partitions on their own HIP streams (default: 3 on one GPU, 2 per rank in a multi-GPU run, "
+                         "1 when the batch does not fill the CUs)")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,7 +187,9 @@ def main():
                                     trace_len=args.trace_len, rank=rank, traffic=args.traffic)
     env = wl.env
     batch = env.B
-    parts = args.partitions if args.partitions is not None else (3 if batch >= 2048 else 1)
+    # partitions: 3 measured best on one GPU (caller's stream + 2); a process has 4 hardware queues and RCCL wants some
+    # of them in a multi-rank run, so there 2 (caller's stream + 1; within 2 % of 3 on one GPU)
+    parts = args.partitions if args.partitions is not None else ((3 if world == 1 else 2) if batch >= 2048 else 1)
     env.set_partitions(parts)
     env.reset()
     env.rollout(max(1, args.warmup))
