@@ -9,8 +9,14 @@ from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
 wl, _ = make_bench_workload(2, torch.device("cuda", 0), n_traces=100, trace_len=100)
 env = wl.env
 env.reset()
-for _ in range(30):
-    env.step()
+parts = int(os.environ.get("RANENV_PARTS", "1"))
+if parts > 1:
+    env.set_partitions(parts)
+    env.rollout(60)
+    print(f"(rollout over {parts} partitions)")
+else:
+    for _ in range(30):
+        env.step()
 torch.cuda.synchronize()
 st = env.views()["policy_scores"].cpu().numpy()[:, :8] * 0.01      # us
 t0 = st[:, 0].min()
