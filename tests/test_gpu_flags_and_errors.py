@@ -336,3 +336,65 @@ def test_trainer_adapters():
     with pytest.raises(ValueError):
         venv.step(np.zeros((3, S)))
     venv.close()
+
+
+def test_degenerate_scenarios_vs_oracle():
+    """No active slice at all (IBSched.action_format's `if np.sum(basestation_slice_assoc) != 0` guard,
+    agents/ib_sched.py:240-246: the allocation stays all-zero), an active slice without UEs, a single UE owning every
+    RB, and all of it next to an ordinary scenario in one batch: against the oracle, all four policies."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables, generate_scaled_scenarios, slice_template_dict
+    from oracle import pyoracle
+    S, U, R, G, Us, steps = 5, 25, 135, 5, 5, 8
+    tabs = ScenarioTables.empty(4, S, U, Us)                                    # row 0: nothing active
+    bsa = np.zeros((1, S)); sua = np.zeros((S, U)); bsa[0, 2] = 1               # row 1: slice 2 active, but no UE in it
+    req = {f"slice_{s}": {} for s in range(S)}; req["slice_2"] = slice_template_dict(1)
+    tabs.set_from_reference(1, bsa, sua, req, True)
+    bsa = np.zeros((1, S)); sua = np.zeros((S, U)); bsa[0, 4] = 1; sua[4, 7] = 1  # row 2: one slice, one UE
+    req = {f"slice_{s}": {} for s in range(S)}; req["slice_4"] = slice_template_dict(5)
+    tabs.set_from_reference(2, bsa, sua, req, True)
+    ordinary = generate_scaled_scenarios(1, seed=9, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=3, min_ues=2)
+    for k, v in ordinary.arrays().items():
+        getattr(tabs, k)[3] = v[0]
+    B = 4
+    rng = np.random.default_rng(2)
+    se_pool = np.stack([se_tile(21, t, U, R) for t in range(steps)])
+    trf = np.stack([poisson_traffic_rows(tabs, b, rng, steps) for b in range(B)])       # [B, steps, U]
+    for policy, intra in ((1, 0), (2, 1), (2, 2), (0, 255)):
+        env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us, n_scenarios=4, max_steps=steps)
+        env.load_scenarios(tabs)
+        env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se_pool, -1, -2)), device=env.device))
+        env.bind_traffic_pool(torch.as_tensor(trf.reshape(B * steps, U).astype(np.int32), device=env.device))
+        env.set_episodes(scenario=np.arange(B), se_base=0, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
+        env.set_policy(policy, intra)
+        cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+        oenvs = []
+        for b in range(B):
+            o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, b); o.reset(se_pool[0]); oenvs.append(o)
+        env.reset()
+        for t in range(steps):
+            if policy == 0:
+                sc = rng.uniform(-1, 1, (B, S)); ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+                obs, rew, done = env.step(sc, ic)
+            else:
+                obs, rew, done = env.step()
+            g = {k: x.cpu().numpy() for k, x in env.views().items()}
+            for b, o in enumerate(oenvs):
+                if policy == 0:
+                    scb, icb = sc[b], ic[b].astype(np.int32)
+                else:
+                    scb = o.policy_mapf() if policy == 2 else o.policy_marr()
+                    icb = np.full(S, intra, dtype=np.int32)
+                _, count, _ = o.action_format(scb, icb, want_dense=False)
+                assert np.array_equal(g["rb_count"][b], count), (policy, t, b)
+                o.step(scb, icb, se_pool[t], trf[b, t])
+                raw, oo = o.raw(), o.obs()
+                for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                    assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (policy, t, b, name)
+                np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=1e-5)
+                np.testing.assert_allclose(obs["obs_intra"][b].cpu().numpy(), oo["obs_intra"], rtol=0, atol=1e-5)
+                np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=1e-9)
+            assert int(g["rb_count"][0].sum()) == 0 and int(g["rb_count"][1].sum()) == 0      # nobody to give RBs to
+            assert int(g["rb_count"][2, 7]) == R and int(g["rb_count"][2].sum()) == R          # one UE owns the carrier
+        env.close()
