@@ -959,10 +959,17 @@ DEVFN void step_body(const KP &p)
     RANENV_STAMP(5);
     __syncthreads();
     RANENV_STAMP(6);
-#if RANENV_DIAG == 4 || RANENV_DIAG == 5
-    if (my_full >= -1.0) return;
-#endif
     do {
+#if RANENV_DIAG == 4 || RANENV_DIAG == 5   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
+    if (my_full >= -1.0) {
+        if (tid == 0) {
+            ST_step_no(p)[e] = (MODE == MODE_RESET) ? 0 : t + 1; ST_hist_len(p)[e] = hlen_new; ST_n_push(p)[e] = npush + 1 == D ? 0 : npush + 1;
+            ST_se_pos(p)[e] = (MODE == MODE_RESET) ? ep.se_offset : (se_pos + 1 >= ep.se_len ? 0 : se_pos + 1);
+            ST_trf_pos(p)[e] = (MODE == MODE_RESET) ? ep.trf_offset : (trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1);
+        }
+        break;
+    }
+#endif
     if (tid >= GRP) break;                   // (3) is done by threads 0..15 (one wave)
 
     // ---- thread t < 16: slice at sorted position t (ib_sched.py:91) --------------------------------
