@@ -733,6 +733,9 @@ DEVFN void step_body(const KP &p)
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
     if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
+#if RANENV_DIAG == 6 || RANENV_DIAG == 7     /* ablations: 6 = entry + stream only (ranges from the stored allocation, sums written out); 7 = no allocation */
+    if (MODE == MODE_STEP) pre = true;
+#endif
     if (pre) {
         rb_start = ST_next_rb_start(p)[su]; rb_count = ST_next_rb_count(p)[su];
 #if RANENV_DIAG != 9
@@ -795,21 +798,16 @@ DEVFN void step_body(const KP &p)
     double sem_new = 0.0;
     bool prev_empty = total == 0;
     if (total != 0 && !((double)total > 2e-8 * (double)max_pkts)) prev_empty = d_isclose((double)total / (double)max_pkts, 0.0);
-#if RANENV_DIAG == 3 || RANENV_DIAG == 5
+#if RANENV_DIAG == 6
+    if (act) { ST_se_mean(p)[su] = my_full; ST_queue_age_sum(p)[su] = (long long)my_part; }
+#endif
+#if RANENV_DIAG == 6
+    if (false) {
+#elif RANENV_DIAG == 3 || RANENV_DIAG == 5
     if (act && my_full < -1.0) {
 #else
     if (act) {
 #endif
-        // slice row for the drift, from the tables parked in LDS
-        int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
-        int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
-        double pv[3] = {0.0, 0.0, 0.0};
-        if (slc >= 0) {
-            const int *si = sh.si[slc];
-            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { pm[k] = sh.pi[slc][2 * k]; po[k] = sh.pi[slc][2 * k + 1]; pv[k] = sh.pf[slc][k]; }
-        }
         if (MODE == MODE_DENSE) {
             const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
             bool seen = false;
@@ -818,7 +816,7 @@ DEVFN void step_body(const KP &p)
             }
         }
         const double se_mean_new = my_full / (double)R, se_part = my_part;
-        long long dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;
+        int dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;     // all < 2^31 (host validates the packet counts)
         if (MODE != MODE_RESET) {
             const double psz = (double)pkt_size;
             // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
@@ -826,7 +824,7 @@ DEVFN void step_body(const KP &p)
                 // MultSliceTraffic.step (traffics/mult_slice.py:24-32): Poisson(slice Mbps) * 1e6 bits for the UEs of a
                 // slice that has a request, 0 elsewhere; drawn here instead of replayed
                 traffic = 0.0;
-                if (slc >= 0 && has_req && sh.sf[slc][1] > 0.0) {
+                if (slc >= 0 && sh.si[slc][1] != 0 && sh.sf[slc][1] > 0.0) {
                     unsigned rnd[4];
                     philox4x32_10((unsigned)(p.env_id_base + e), (unsigned)episode_no, (unsigned)t, (unsigned)u,
                                   (unsigned)p.trf_seed, (unsigned)(p.trf_seed >> 32), rnd);
@@ -854,25 +852,25 @@ DEVFN void step_body(const KP &p)
                 if (nent > 0) load_head();
             }
             sum_age += total;                                     // everything left ages one TTI
-            const long long space = (long long)max_pkts - total;  // arrivals admitted up to capacity
-            const long long adm = pkt_in < space ? pkt_in : space;
+            const int space = max_pkts - total;                   // arrivals admitted up to capacity
+            const int adm = pkt_in < space ? pkt_in : space;
             dropped += pkt_in - adm;
             if (adm > 0) {
                 int tail = head + nent; tail = tail >= L ? tail - L : tail;
-                ring[(size_t)tail * U] = make_int2(t, (int)adm);
-                if (nent == 0) { front = t; front_rem = (int)adm; }
+                ring[(size_t)tail * U] = make_int2(t, adm);
+                if (nent == 0) { front = t; front_rem = adm; }
                 nent++;
-                total += (int)adm;
+                total += adm;
             }
-            long long cap = pkt_thr;                              // send: drain oldest first
+            int cap = pkt_thr;                                    // send: drain oldest first
             while (cap > 0 && nent > 0) {
-                const long long take = cap < front_rem ? cap : front_rem;
-                front_rem -= (int)take; total -= (int)take; cap -= take; sent += take;
+                const int take = cap < front_rem ? cap : front_rem;
+                front_rem -= take; total -= take; cap -= take; sent += take;
                 sum_age -= (long long)(t - front) * take;
                 if (front_rem == 0) {
                     pop_head();
                     if (nent > 0) {
-                        if (nent == 1 && adm > 0) { front = t; front_rem = (int)adm; }   // this TTI's entry
+                        if (nent == 1 && adm > 0) { front = t; front_rem = adm; }   // this TTI's entry
                         else load_head();
                     }
                 }
@@ -899,6 +897,18 @@ DEVFN void step_body(const KP &p)
         // slices, so "for each parameter: switch on its metric" would run all three formulas three times.
         // Instead: find this slice's (value, operator) for each metric, then run each formula once.
         double dres[3] = {0.0, 0.0, 0.0};
+        // slice row for the drift, from the tables parked in LDS (read here, not at the top of the role: 17 registers
+        // that would otherwise be alive through the buffer update)
+        asm volatile("" ::: "memory");
+        int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
+        int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
+        double pv[3] = {0.0, 0.0, 0.0};
+        if (slc >= 0) {
+            const int *si = sh.si[slc];
+            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { pm[k] = sh.pi[slc][2 * k]; po[k] = sh.pi[slc][2 * k + 1]; pv[k] = sh.pf[slc][k]; }
+        }
         if (slc >= 0 && has_req) {
             const double o = p.over;
             bool dec[3] = {false, false, false};
@@ -960,8 +970,12 @@ DEVFN void step_body(const KP &p)
     __syncthreads();
     RANENV_STAMP(6);
     do {
-#if RANENV_DIAG == 4 || RANENV_DIAG == 5   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
+#if RANENV_DIAG == 4 || RANENV_DIAG == 5 || RANENV_DIAG == 6   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
+#if RANENV_DIAG == 6
+    if (true) {
+#else
     if (my_full >= -1.0) {
+#endif
         if (tid == 0) {
             ST_step_no(p)[e] = (MODE == MODE_RESET) ? 0 : t + 1; ST_hist_len(p)[e] = hlen_new; ST_n_push(p)[e] = npush + 1 == D ? 0 : npush + 1;
             ST_se_pos(p)[e] = (MODE == MODE_RESET) ? ep.se_offset : (se_pos + 1 >= ep.se_len ? 0 : se_pos + 1);
@@ -1086,6 +1100,9 @@ DEVFN void step_body(const KP &p)
     // ---- (0') the next TTI's allocation, from the state this step leaves behind ----------------------
     bool late = false;
     if (MODE == MODE_STEP) late = p.scores == nullptr && (p.late == 2 || (p.late == 1 && (((unsigned)e * 0x9E3779B1u) >> 16 & 1u)));
+#if RANENV_DIAG == 6 || RANENV_DIAG == 7
+    if (MODE == MODE_STEP) late = false;
+#endif
     if (late) {
         __syncthreads();                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
