@@ -1,0 +1,128 @@
+"""Seeded fuzz of the step kernel against the CPU oracle: shapes, window depths, age caps, load levels and the way the
+TTIs are issued (caller's scores, device policy step by step, device policy as a rollout over partitions) are drawn
+from a fixed seed, so a failure reproduces from its case number.  Bars as everywhere: integers bit-exact, float32
+observations within 1e-5, float64 rewards within 1e-9.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.common import poisson_traffic_rows
+from tests.synth import se_tile
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL = 1e-5
+REW_TOL = 1e-9
+N_CASES = 24
+
+
+def _draw_case(k):
+    rng = np.random.default_rng(9000 + k)
+    S = int(rng.integers(1, 17))
+    Us = int(rng.integers(1, 17))
+    U = int(rng.integers(max(2, Us), 257))
+    G = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    # every numpy pairwise shape: below 8, one leaf with and without tail, two, three and four leaves
+    R = int(rng.choice([rng.integers(G, 8 * G + 1), rng.integers(8, 129), rng.integers(129, 257), rng.integers(257, 489)]))
+    R = max(R, G)
+    D = int(rng.choice([10, 10, 1, 2, 7]))
+    load = float(rng.choice([0.2, 1.0, 1.0, 6.0]))        # multiplies the Poisson rows: idle, nominal, congested
+    low_se = int(rng.choice([0, 0, 3]))                  # every third UE has nearly no capacity
+    how = ["external", "device_steps", "device_rollout"][k % 3]
+    policy, intra = [(2, 1), (1, 0), (2, 2), (2, 0)][int(rng.integers(0, 4))]
+    return dict(S=S, U=U, R=R, G=G, Us=Us, D=D, load=load, low_se=low_se, how=how, policy=policy, intra=intra)
+
+
+@pytest.mark.parametrize("k", range(N_CASES))
+@pytest.mark.parametrize("build", ["lean", "small"])
+def test_fuzz_case_vs_oracle(k, build, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if build == "lean" else "1")
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    from oracle import pyoracle
+    c = _draw_case(k)
+    S, U, R, G, Us, D = c["S"], c["U"], c["R"], c["G"], c["Us"], c["D"]
+    rng = np.random.default_rng(500 + k)
+    min_ues = max(1, Us // 3)
+    # the generator needs room for its smallest scenario
+    n_sl_min = max(1, min(S, U // max(1, Us)) // 2)
+    tabs = generate_scaled_scenarios(4, seed=40 + k, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=n_sl_min, min_ues=min_ues)
+    B, steps = 7, 12
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    se_pool = np.stack([se_tile(300 + k, t, U, R, low_se_every=c["low_se"]) for t in range(B * steps)])
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)]) * c["load"]
+    trf = np.floor(trf)
+    env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+                        n_scenarios=tabs.n_scenarios, max_steps=steps, hist_depth=D)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se_pool, -1, -2)), device=env.device))
+    env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
+    ocfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps, hist_depth=D)
+    oenvs = []
+    for b in range(B):
+        o = pyoracle.OracleEnv(ocfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
+    if c["how"] == "external":
+        env.set_policy(0, 255)
+    else:
+        env.set_policy(c["policy"], c["intra"])
+    intra_fixed = c["intra"]
+    env.reset()
+
+    def oracle_step(t, sc, ic):
+        exp = []
+        for b, o in enumerate(oenvs):
+            _, count, _ = o.action_format(sc[b], ic[b], want_dense=False)
+            o.step(sc[b], ic[b], se_pool[b * steps + t], trf[b * steps + t])
+            exp.append((count, o.raw(), o.obs()))
+        return exp
+
+    def compare(t, exp, obs, rew):
+        g = {n: x.cpu().numpy() for n, x in env.views().items()}
+        for b, (count, raw, oo) in enumerate(exp):
+            tag = (k, c, t, b)
+            assert np.array_equal(g["rb_count"][b], count), tag
+            for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (tag, name)
+            if obs is not None:
+                np.testing.assert_allclose(obs["obs_inter"][b].cpu().numpy(), oo["obs_inter"], rtol=0, atol=OBS_TOL, err_msg=str(tag))
+                np.testing.assert_allclose(obs["obs_intra"][b].cpu().numpy(), oo["obs_intra"], rtol=0, atol=OBS_TOL, err_msg=str(tag))
+                np.testing.assert_allclose(rew[b].cpu().numpy(), oo["reward"], rtol=0, atol=REW_TOL, err_msg=str(tag))
+
+    def device_scores():
+        if c["policy"] == 1:
+            return np.stack([o.policy_marr() for o in oenvs])
+        return np.stack([o.policy_mapf() for o in oenvs])
+
+    if c["how"] == "device_rollout":
+        env.set_partitions(3)
+        exp = None
+        for t in range(steps):
+            exp = oracle_step(t, device_scores(), np.full((B, S), intra_fixed, dtype=np.uint8))
+        obs, rew, done = env.rollout(steps)
+        torch.cuda.synchronize()
+        compare(steps - 1, exp, obs, rew)
+        g = {n: x.cpu().numpy() for n, x in env.views().items()}
+        ro = {n: x.cpu().numpy() for n, x in env.raw_observation().items()}
+        for b, o in enumerate(oenvs):
+            raw = o.raw()
+            assert np.array_equal(ro["buffer_occupancies"][b], raw["buffer_occupancies"]), (k, c, b)
+            assert np.array_equal(ro["buffer_latencies"][b], raw["buffer_latencies"]), (k, c, b)
+    else:
+        for t in range(steps):
+            if c["how"] == "external":
+                sc = rng.uniform(-1, 1, (B, S))
+                sc[rng.random((B, S)) < 0.15] = -1.0
+                ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+                exp = oracle_step(t, sc, ic)
+                obs, rew, done = env.step(sc, ic)
+            else:
+                sc = device_scores(); ic = np.full((B, S), intra_fixed, dtype=np.uint8)
+                exp = oracle_step(t, sc, ic)
+                obs, rew, done = env.step()
+            compare(t, exp, obs, rew)
+    env.close()
