@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 4
+#define RANENV_ABI_VERSION 5
 
 enum {
     RANENV_OK = 0,
@@ -224,6 +224,25 @@ int ranenv_set_partitions(ranenv_handle h, int32_t n_parts);
  * TTI t directly.  The outputs hold the last TTI's values.  Needs a device policy and bound pools / generator. */
 int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *dev_obs_inter, float *dev_obs_intra,
                    double *dev_reward, uint8_t *dev_done, void *stream);
+/* With auto-reset enabled (ranenv_set_autoreset below) the rollout runs through episode ends: an env whose episode
+ * finishes at a TTI gets its next episode installed and CommunicationEnv.reset applied right behind that TTI's step,
+ * on its partition's stream, before its next TTI -- the reference's evaluation loop over many episodes
+ * (simu.py:547-566) without the host between two TTIs.  dev_done is required then. */
+
+/* Episode metrics on the device (what the paper's evaluation derives per TTI from the history files,
+ * results/gen_results.py:874-1022, kept as running sums so that a rollout needs no per-TTI read-back).  Per env 8
+ * float64 sums over the TTIs of the current episode (a reset zeroes them):
+ *   [0] TTIs   [1] inter-slice reward (player_0, calculate_reward_no_mask)
+ *   [2] active slices in violation (minimum declared intent drift < 0)      [3] the same, priority slices only
+ *   [4] distance to fulfilment: sum over slices of their negative minimum drift   [5] priority slices only
+ *   [6] packets sent (pkt_effective_thr over the UEs)    [7] packets dropped
+ * When an episode ends under auto-reset, its sums are appended to the env's log of episode_slots rows (later episodes
+ * are only counted).  ranenv_enable_metrics(h, slots >= 0) allocates, zeroes and switches on; slots < 0 switches off.
+ * ranenv_get_metrics returns device pointers: running [B][8], episode_log [B][slots][8] (NULL if slots == 0),
+ * episodes_done [B] int32. */
+int ranenv_enable_metrics(ranenv_handle h, int32_t episode_slots, void *stream);
+int ranenv_get_metrics(ranenv_handle h, double **dev_running, double **dev_episode_log, int32_t **dev_episodes_done,
+                       int32_t *episode_slots);
 
 int ranenv_get_views(ranenv_handle h, ranenv_views *out);
 

@@ -423,13 +423,41 @@ class BatchedRanEnv:
         """``n_steps`` TTIs under the device policy enqueued in one call (MARR / MAPF evaluation runs): the launches of
         ``n_steps`` calls of ``step()``, joined with the current stream only before the first and after the last TTI.
         Returns the last TTI's (obs, reward, done)."""
-        if self._recorder is not None or self._autoreset:
-            raise RanEnvError("rollout() does not return between TTIs: the recorder and auto-reset need step()")
+        if self._recorder is not None:
+            raise RanEnvError("rollout() does not return between TTIs: the recorder needs step()")
         st = self._lib.ranenv_rollout(self._h, int(n_steps), *self._p_out,
                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if st != 0:
             self._check(st, "ranenv_rollout")
         return self._obs(), self.reward, self.done
+
+    METRIC_NAMES = ("ttis", "reward", "violations", "priority_violations", "distance", "priority_distance",
+                    "pkts_sent", "pkts_dropped")
+
+    def enable_metrics(self, episode_slots: int = 0) -> None:
+        """Per-env running sums over the TTIs of the current episode, kept by the step kernel (include/ranenv.h:
+        TTIs, inter-slice reward, slices in violation and distance to fulfilment for all / priority slices -- the
+        quantities results/gen_results.py:874-1022 derives from the history files -- and packets sent / dropped).
+        With auto-reset a finished episode's sums are appended to the env's log of ``episode_slots`` rows."""
+        self._check(self._lib.ranenv_enable_metrics(self._h, int(episode_slots), self._stream()), "ranenv_enable_metrics")
+        self._metric_views = None
+
+    def disable_metrics(self) -> None:
+        self._check(self._lib.ranenv_enable_metrics(self._h, -1, self._stream()), "ranenv_enable_metrics")
+
+    def episode_metrics(self) -> Dict[str, torch.Tensor]:
+        """Zero-copy views: ``running`` [B, 8] (current episode), ``episode_log`` [B, slots, 8] (finished episodes, in
+        order; absent with 0 slots), ``episodes_done`` [B]; columns as METRIC_NAMES."""
+        if getattr(self, "_metric_views", None) is None:
+            run, log, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            slots = C.c_int32()
+            self._check(self._lib.ranenv_get_metrics(self._h, C.byref(run), C.byref(log), C.byref(n), C.byref(slots)), "ranenv_get_metrics")
+            out = {"running": torch.as_tensor(_DevArray(run.value, (self.B, 8), "f8", self), device=self.device),
+                   "episodes_done": torch.as_tensor(_DevArray(n.value, (self.B,), "i4", self), device=self.device)}
+            if slots.value > 0:
+                out["episode_log"] = torch.as_tensor(_DevArray(log.value, (self.B, slots.value, 8), "f8", self), device=self.device)
+            self._metric_views = out
+        return self._metric_views
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -37,6 +37,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ranenv.h"
@@ -144,6 +145,7 @@ struct KP {
     const unsigned long long *pois_cdf;   // [NS][S][256] floor(P(X <= k) * 2^64), saturated
     const uint8_t *pois_guide;            // [NS][S][64]  smallest k with cdf[k] > j * 2^58
     const int32_t *max_steps_env;         // [B] per-env episode length or null (= max_steps)
+    double *acc;                          // [B][8] running sums of the current episode (ranenv_enable_metrics) or null
     // per-call inputs (may be null)
     const uint8_t *env_mask;
     const double *scores; const uint8_t *intra; const double *traffic_bits; const float *se_tiles;
@@ -221,6 +223,34 @@ DEVFN int row16_sum(int x)          // every lane gets the sum of its row: rotat
     x += dpp_row<0x121>(x); x += dpp_row<0x122>(x); x += dpp_row<0x124>(x); x += dpp_row<0x128>(x);
     return x;
 }
+DEVFN double row16_sum_f64(double x)  // the same for a double (two 32-bit moves per step); a fixed tree, not numpy's order
+{
+    auto rot = [](double v, auto ctrl) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = dpp_row<decltype(ctrl)::value>((int)b), hi = dpp_row<decltype(ctrl)::value>((int)(b >> 32));
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    };
+    x += rot(x, std::integral_constant<int, 0x121>{}); x += rot(x, std::integral_constant<int, 0x122>{});
+    x += rot(x, std::integral_constant<int, 0x124>{}); x += rot(x, std::integral_constant<int, 0x128>{});
+    return x;
+}
+DEVFN double wave_sum_f64(double x)   // sum over the 64 lanes of the wave (all active): rows by DPP, then the four row sums
+{
+    x = row16_sum_f64(x);
+    auto lane = [](double v, int l) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    return (lane(x, 0) + lane(x, 16)) + (lane(x, 32) + lane(x, 48));
+}
+// global_atomic_add_f64 without a return value: nothing waits for it (the library is built with the atomic optimizer
+// off: every add here already comes from one lane)
+DEVFN void acc_add(double *p, double v)
+{
+    typedef __attribute__((address_space(1))) double *gptr;
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gptr)p, v);
+}
 DEVFN int row16_scan(int x)         // inclusive prefix sum: shift right by 1, 2, 4, 8 (zeros shifted in)
 {
     x += dpp_row<0x111>(x); x += dpp_row<0x112>(x); x += dpp_row<0x114>(x); x += dpp_row<0x118>(x);
@@ -274,6 +304,9 @@ DEVFN RowPlan make_row_plan(int n)
                                   the queue's last turn, 2: after the stream (default: ~20 registers fewer while the tile
                                   streams; with 8 loads in flight per lane the kernel fits 96 VGPRs = 5 waves per SIMD
                                   without spills; measured A/B in profiles/r02_ab_log.txt) */
+#endif
+#ifndef RANENV_METRICS
+#define RANENV_METRICS 1           /* 0 compiles the episode-metric sums out (A/B of their cost only) */
 #endif
 #ifndef RANENV_LATE_DEFAULT
 #define RANENV_LATE_DEFAULT 1
@@ -796,6 +829,7 @@ DEVFN void step_body(const KP &p)
     // np.isclose(previous buffer occupancy, 0) (common.py:108-118): occupancy = total / max_pkts.  Exact
     // shortcuts: an empty queue is 0; a queue above 2e-8 * max_pkts is not close to 0; in between, divide.
     double sem_new = 0.0;
+    int sent_u = 0, drop_u = 0;              // this UE's packets sent / dropped (episode metrics)
     bool prev_empty = total == 0;
     if (total != 0 && !((double)total > 2e-8 * (double)max_pkts)) prev_empty = d_isclose((double)total / (double)max_pkts, 0.0);
 #if RANENV_DIAG == 6
@@ -887,6 +921,7 @@ DEVFN void step_body(const KP &p)
         if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
             ST_pkt_incoming(p)[su] = (int32_t)pkt_in; ST_pkt_throughputs(p)[su] = (int32_t)pkt_thr;
         }
+        sent_u = sent; drop_u = dropped;
 
         ST_se_mean(p)[su] = se_mean_new; sem_new = se_mean_new;
         ST_rb_start(p)[su] = rb_start; ST_rb_count(p)[su] = rb_count;
@@ -964,6 +999,11 @@ DEVFN void step_body(const KP &p)
                 oa[9 + Us + ue_pos] = (float)(se_mean_new / p.norm_se);
             }
         }
+    }
+    if (MODE != MODE_RESET && (RANENV_METRICS && p.acc != nullptr)) {
+        // episode metrics: packet totals of the env, one add per wave (integers in doubles: exact in any order)
+        const double ws = wave_sum_f64((double)sent_u), wd = wave_sum_f64((double)drop_u);
+        if ((tid & (WAVE - 1)) == 0) { acc_add(p.acc + (size_t)e * 8 + 6, ws); acc_add(p.acc + (size_t)e * 8 + 7, wd); }
     }
     if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
     RANENV_STAMP(5);
@@ -1070,6 +1110,12 @@ DEVFN void step_body(const KP &p)
     }
     const int mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
     const double my_ao = xr[0][tid], my_pr = xr[1][tid];
+    // episode metrics: distance to fulfilment = sum of the negative slice drifts (entries beyond S are 0), all slices and
+    // priority slices (priority is 0 or 1), as a fixed tree over the 16 lanes
+    double dist = 0.0, prio_dist = 0.0;
+    if (MODE != MODE_RESET && (RANENV_METRICS && p.acc != nullptr)) {
+        dist = row16_sum_f64(fmin(my_ao, 0.0)); prio_dist = row16_sum_f64(fmin(my_ao * my_pr, 0.0));
+    }
     const bool my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
     const unsigned gm = (unsigned)(__ballot(my_sel) & 0xffffull);
     const int m_sel = __popc(gm), cslot = __popc(gm & ((1u << tid) - 1u));
@@ -1081,6 +1127,19 @@ DEVFN void step_body(const KP &p)
         double rew = np_sum16_lds(xr[2], m_sel) / (double)m_sel;
         if (mode_sel == 1) rew -= 1.0;
         if (p.reward) p.reward[(size_t)e * (S + 1)] = rew;
+        // Episode metrics (ranenv_enable_metrics): running sums of what the paper's evaluation reads per TTI
+        // (results/gen_results.py:874-1022: slices in violation, distance to fulfilment, all slices / priority slices
+        // only), of the inter-slice reward and of the packet totals.  One writer per env and TTI; fire-and-forget adds.
+        if ((RANENV_METRICS && p.acc != nullptr)) {
+            double *a = p.acc + (size_t)e * 8;
+            if (MODE == MODE_RESET) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) a[k] = 0.0;
+            } else {
+                acc_add(a + 0, 1.0); acc_add(a + 1, rew); acc_add(a + 2, (double)n_neg); acc_add(a + 3, (double)n_prio_neg);
+                acc_add(a + 4, dist); acc_add(a + 5, prio_dist);       // ([6], [7]: by the UE role, one add per wave)
+            }
+        }
         // per-env counters: everything was read as a scalar at kernel entry (hlen already reflects a cleared window)
         const int step_new = (MODE == MODE_RESET) ? 0 : t + 1;
         ST_step_no(p)[e] = step_new;
@@ -1360,14 +1419,21 @@ struct AdvanceArgs {
     int initial, max_ep, random, env_id_base; unsigned long long seed;
     const float *obs_inter, *obs_intra, *head_obs; float *term_inter, *term_intra, *term_head;
     int n_inter, n_intra, n_head;
+    int e0;                                       // first env of this launch (batch partitions)
+    const double *acc; double *ep_acc; int32_t *ep_n; int ep_slots;   // episode metrics: running sums -> per-episode log
 };
 
 __global__ void __launch_bounds__(64) ranenv_advance_kernel(const AdvanceArgs a)
 {
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = a.e0 + blockIdx.x, tid = threadIdx.x;
     const bool d = a.done[e] != 0;
     if (tid == 0) a.mask[e] = d ? 1 : 0;
     if (!d) return;
+    if (a.acc) {          // the finished episode's sums go to the env's log (the reset that follows zeroes the running sums)
+        const int n = a.ep_n[e];                  // read by every thread of this one wave before thread 8 stores
+        if (tid < 8 && n < a.ep_slots) a.ep_acc[((size_t)e * a.ep_slots + n) * 8 + tid] = a.acc[(size_t)e * 8 + tid];
+        if (tid == 8) a.ep_n[e] = n + 1;
+    }
     if (a.term_inter) for (int i = tid; i < a.n_inter; i += 64) a.term_inter[(size_t)e * a.n_inter + i] = a.obs_inter[(size_t)e * a.n_inter + i];
     if (a.term_intra) for (int i = tid; i < a.n_intra; i += 64) a.term_intra[(size_t)e * a.n_intra + i] = a.obs_intra[(size_t)e * a.n_intra + i];
     if (a.term_head && a.head_obs) for (int i = tid; i < a.n_head; i += 64) a.term_head[(size_t)e * a.n_head + i] = a.head_obs[(size_t)e * a.n_head + i];
@@ -1404,6 +1470,8 @@ struct ranenv {
     ranenv_episode *d_ep_table = nullptr; int ep_table_first = 0, ep_table_n = 0;     // auto-reset: episode number -> descriptor
     int ar_initial = 0, ar_max = 0, ar_random = 0; unsigned long long ar_seed = 0; bool ar_on = false;
     uint8_t *d_ar_mask = nullptr;
+    double *d_acc = nullptr, *d_ep_acc = nullptr; int32_t *d_ep_n = nullptr; int ep_slots = 0;   // ranenv_enable_metrics
+    std::vector<int32_t> host_max_steps;        // copy of ranenv_set_max_steps' array (the multi-episode rollout follows the step counters)
     unsigned long long *d_pois_cdf = nullptr; uint8_t *d_pois_guide = nullptr; int32_t *d_max_steps = nullptr;
     std::vector<double> slice_traffic;          // [NS][S] host copy (traffic generator tables)
     std::vector<int32_t> slice_has_req;
@@ -1543,13 +1611,12 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
 // (inputs), `join_out` orders the caller's stream behind them (outputs).  ranenv_rollout enqueues n TTIs with a join
 // only before the first and after the last: partition k's TTI t+1 then follows its own TTI t directly, whatever the
 // other partitions are doing -- envs are independent, nothing else orders them.
-template <int MODE>
-hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = true, bool join_out = true)
+template <typename Body>      // Body(e0, n, stream) -> hipError_t: what one partition enqueues for one TTI
+hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, bool join_out, Body body)
 {
-    kp.alloc_gen = h->alloc_gen;
     hipError_t le = hipSuccess;
     if (h->n_parts <= 1) {
-        le = launch_range<MODE>(h, kp, 0, kp.B, stream);
+        le = body(0, h->cfg.batch, stream);
         if (le != hipSuccess) return le;
         // RANENV_F_SYNC_CHECK: surface asynchronous kernel faults at the call that caused them
         if (h->cfg.flags & RANENV_F_SYNC_CHECK) return hipStreamSynchronize(stream);
@@ -1564,11 +1631,11 @@ hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = tru
     for (int k = 1; k < h->n_parts; k++) {
         hipStream_t ps = h->part_stream[k];
         if (join_in) { le = hipStreamWaitEvent(ps, h->ev_in, 0); if (le != hipSuccess) return le; }
-        le = launch_range<MODE>(h, kp, h->part_lo[k], h->part_lo[k + 1] - h->part_lo[k], ps);
+        le = body(h->part_lo[k], h->part_lo[k + 1] - h->part_lo[k], ps);
         if (le != hipSuccess) return le;
         if (join_out) { le = hipEventRecord(h->part_done[k], ps); if (le != hipSuccess) return le; }
     }
-    le = launch_range<MODE>(h, kp, h->part_lo[0], h->part_lo[1] - h->part_lo[0], stream);
+    le = body(h->part_lo[0], h->part_lo[1] - h->part_lo[0], stream);
     if (le != hipSuccess) return le;
     if (join_out)
         for (int k = 1; k < h->n_parts; k++) { le = hipStreamWaitEvent(stream, h->part_done[k], 0); if (le != hipSuccess) return le; }
@@ -1578,6 +1645,32 @@ hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = tru
         return le;
     }
     return hipSuccess;
+}
+
+template <int MODE>
+hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = true, bool join_out = true)
+{
+    kp.alloc_gen = h->alloc_gen;
+    return for_partitions(h, stream, join_in, join_out,
+                          [&](int e0, int n, hipStream_t s) { return launch_range<MODE>(h, kp, e0, n, s); });
+}
+
+// Auto-reset: the arguments of the advance kernel for this handle's tables and the caller's buffers
+AdvanceArgs advance_args(ranenv_handle h, const uint8_t *dev_done, float *obs_inter, float *obs_intra,
+                         float *term_obs_inter, float *term_obs_intra, float *term_obs_head)
+{
+    const int S = h->cfg.n_slices, Us = h->cfg.max_ues_slice;
+    AdvanceArgs a;
+    a.done = dev_done; a.mask = h->d_ar_mask; a.episodes = h->d_episodes; a.table = h->d_ep_table;
+    a.table_first = h->ep_table_first; a.table_n = h->ep_table_n;
+    a.episode_no = ST_episode_no(h->kp); a.reset_count = ST_reset_count(h->kp);
+    a.initial = h->ar_initial; a.max_ep = h->ar_max; a.random = h->ar_random; a.env_id_base = h->kp.env_id_base; a.seed = h->ar_seed;
+    a.obs_inter = obs_inter; a.obs_intra = obs_intra; a.head_obs = h->kp.head_obs;
+    a.term_inter = obs_inter ? term_obs_inter : nullptr; a.term_intra = obs_intra ? term_obs_intra : nullptr; a.term_head = term_obs_head;
+    a.n_inter = S * 10; a.n_intra = S * (2 * Us + 9); a.n_head = S * 10;
+    a.e0 = 0;
+    a.acc = h->kp.acc; a.ep_acc = h->d_ep_acc; a.ep_n = h->d_ep_n; a.ep_slots = h->ep_slots;
+    return a;
 }
 
 }  // namespace
@@ -1927,10 +2020,72 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     KP kp = h->kp;
     kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
+    hipStream_t stream = (hipStream_t)stream_;
+    kp.alloc_gen = h->alloc_gen;
+    // With auto-reset on, an env whose episode ends inside the rollout moves on to its next episode without the host:
+    // the advance kernel + the step kernel in RESET mode follow that TTI's step on the partition's stream.  They are only
+    // enqueued for TTIs at which some env of the partition finishes: the step counters are read once here and followed
+    // on the host (nothing but this rollout changes them until it returns).
+    std::vector<int32_t> steps;
+    AdvanceArgs adv{};
+    KP kpr = kp;
+    if (h->ar_on) {
+        if (!done) return fail(h, RANENV_E_INVALID, "a rollout with auto-reset needs the done buffer");
+        steps.resize((size_t)h->cfg.batch);
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        HIP_TRY(h, hipMemcpy(steps.data(), ST_step_no(h->kp), sizeof(int32_t) * steps.size(), hipMemcpyDeviceToHost));
+        adv = advance_args(h, done, obs_inter, obs_intra, nullptr, nullptr, nullptr);
+        kpr.env_mask = h->d_ar_mask; kpr.reward = nullptr; kpr.done = nullptr;
+    }
+    const bool follow = h->ar_on;
     for (int i = 0; i < n_steps; i++) {
-        const hipError_t e = launch<MODE_STEP>(h, kp, (hipStream_t)stream_, i == 0, i == n_steps - 1);
+        const hipError_t e = for_partitions(h, stream, i == 0, i == n_steps - 1, [&](int e0, int n, hipStream_t s) -> hipError_t {
+            hipError_t le = launch_range<MODE_STEP>(h, kp, e0, n, s);
+            if (le != hipSuccess || !follow) return le;
+            bool any = false;
+            for (int b = e0; b < e0 + n; b++) {
+                const int32_t m = h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b];
+                if (++steps[(size_t)b] >= m) { any = true; steps[(size_t)b] = 0; }
+            }
+            if (!any) return hipSuccess;
+            AdvanceArgs a = adv; a.e0 = e0;
+            hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
+            return launch_range<MODE_RESET>(h, kpr, e0, n, s);
+        });
         if (e != hipSuccess) return fail(h, RANENV_E_HIP, "rollout launch %d: %s", i, hipGetErrorString(e));
     }
+    return RANENV_OK;
+}
+
+int ranenv_enable_metrics(ranenv_handle h, int32_t episode_slots, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (episode_slots < 0) { h->kp.acc = nullptr; return RANENV_OK; }      // off (what was accumulated stays readable)
+    if (h->d_acc && episode_slots != h->ep_slots)
+        return fail(h, RANENV_E_STATE, "episode metrics were enabled with %d slots per env", h->ep_slots);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t B = (size_t)h->cfg.batch;
+    if (!h->d_acc) {
+        if (dev_alloc(h, &h->d_acc, B * 8) != RANENV_OK || dev_alloc(h, &h->d_ep_n, B) != RANENV_OK) return RANENV_E_NOMEM;
+        if (episode_slots > 0 && dev_alloc(h, &h->d_ep_acc, B * (size_t)episode_slots * 8) != RANENV_OK) return RANENV_E_NOMEM;
+        h->ep_slots = episode_slots;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_acc, 0, sizeof(double) * B * 8, stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_ep_n, 0, sizeof(int32_t) * B, stream));
+    if (h->d_ep_acc) HIP_TRY(h, hipMemsetAsync(h->d_ep_acc, 0, sizeof(double) * B * (size_t)h->ep_slots * 8, stream));
+    h->kp.acc = h->d_acc;
+    return RANENV_OK;
+}
+
+int ranenv_get_metrics(ranenv_handle h, double **dev_running, double **dev_episode_log, int32_t **dev_episodes_done, int32_t *episode_slots)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (!h->d_acc) return fail(h, RANENV_E_STATE, "episode metrics are not enabled (ranenv_enable_metrics)");
+    if (dev_running) *dev_running = h->d_acc;
+    if (dev_episode_log) *dev_episode_log = h->d_ep_acc;
+    if (dev_episodes_done) *dev_episodes_done = h->d_ep_n;
+    if (episode_slots) *episode_slots = h->ep_slots;
     return RANENV_OK;
 }
 
@@ -1962,13 +2117,14 @@ int ranenv_set_max_steps(ranenv_handle h, const int32_t *host_max_steps, void *s
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (!host_max_steps) { h->kp.max_steps_env = nullptr; return RANENV_OK; }
+    if (!host_max_steps) { h->kp.max_steps_env = nullptr; h->host_max_steps.clear(); return RANENV_OK; }
     for (int b = 0; b < h->cfg.batch; b++) if (host_max_steps[b] < 1) return fail(h, RANENV_E_INVALID, "env %d: max_steps must be >= 1", b);
     if (!h->d_max_steps && dev_alloc(h, &h->d_max_steps, (size_t)h->cfg.batch) != RANENV_OK) return RANENV_E_NOMEM;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(h->d_max_steps, host_max_steps, sizeof(int32_t) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
     h->kp.max_steps_env = h->d_max_steps;
+    h->host_max_steps.assign(host_max_steps, host_max_steps + h->cfg.batch);
     return RANENV_OK;
 }
 
@@ -2035,15 +2191,7 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
-    const int S = h->cfg.n_slices, Us = h->cfg.max_ues_slice;
-    AdvanceArgs a;
-    a.done = dev_done; a.mask = h->d_ar_mask; a.episodes = h->d_episodes; a.table = h->d_ep_table;
-    a.table_first = h->ep_table_first; a.table_n = h->ep_table_n;
-    a.episode_no = ST_episode_no(h->kp); a.reset_count = ST_reset_count(h->kp);
-    a.initial = h->ar_initial; a.max_ep = h->ar_max; a.random = h->ar_random; a.env_id_base = h->kp.env_id_base; a.seed = h->ar_seed;
-    a.obs_inter = obs_inter; a.obs_intra = obs_intra; a.head_obs = h->kp.head_obs;
-    a.term_inter = obs_inter ? term_obs_inter : nullptr; a.term_intra = obs_intra ? term_obs_intra : nullptr; a.term_head = term_obs_head;
-    a.n_inter = S * 10; a.n_intra = S * (2 * Us + 9); a.n_head = S * 10;
+    const AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;

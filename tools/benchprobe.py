@@ -8,6 +8,8 @@ config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else None
 wl, _ = make_bench_workload(config, torch.device("cuda", 0), batch=batch)
 env = wl.env
+if os.environ.get("RANENV_METRICS") == "1":
+    env.enable_metrics(0)
 env.reset()
 for _ in range(30):
     env.step()
