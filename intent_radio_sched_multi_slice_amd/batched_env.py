@@ -219,10 +219,12 @@ class BatchedRanEnv:
         """Per-env episode length ([B] ints) or None for the constructor's max_steps everywhere."""
         if max_steps is None:
             self._check(self._lib.ranenv_set_max_steps(self._h, None, self._stream()), "ranenv_set_max_steps")
+            self.max_steps_env = None
             return
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(max_steps, dtype=np.int32), (self.B,)))
         with torch.cuda.device(self.device):
             self._check(self._lib.ranenv_set_max_steps(self._h, C.c_void_p(a.ctypes.data), self._stream()), "ranenv_set_max_steps")
+        self.max_steps_env = a.copy()
 
     def set_episode_table(self, scenario, se_base=0, se_len=1, se_offset=0, trf_base=0, trf_len=1, trf_offset=0,
                           first_episode: int = 0):
@@ -458,6 +460,32 @@ class BatchedRanEnv:
                 out["episode_log"] = torch.as_tensor(_DevArray(log.value, (self.B, slots.value, 8), "f8", self), device=self.device)
             self._metric_views = out
         return self._metric_views
+
+    def evaluate(self, n_episodes: int, max_steps=None) -> Dict[str, np.ndarray]:
+        """The reference's test loop for its baseline agents (simu.py:547-566 over ``max_episode - initial_episode``
+        episodes; the numbers results/gen_results.py:874-1022 turns into the paper's violation / distance figures), for
+        the whole batch on the device: reset, then one rollout long enough for every env to finish ``n_episodes``
+        episodes under the device policy, episode ends handled by auto-reset.  Needs enable_autoreset(...) and
+        enable_metrics(slots >= n_episodes).  Returns {metric: float64 [B, n_episodes]} with the names of METRIC_NAMES;
+        row b holds env b's episodes in the order it played them (from the episode number given to enable_autoreset)."""
+        if not self._autoreset:
+            raise RanEnvError("evaluate() needs enable_autoreset(): it runs through episode ends on the device")
+        m = self.episode_metrics()
+        if "episode_log" not in m or m["episode_log"].shape[1] < n_episodes:
+            raise RanEnvError(f"evaluate({n_episodes}) needs enable_metrics(episode_slots >= {n_episodes})")
+        if max_steps is not None:
+            self.set_max_steps(max_steps)
+        me = getattr(self, "max_steps_env", None)
+        longest = int(self.max_steps) if me is None else int(me.max())
+        self.enable_metrics(m["episode_log"].shape[1])      # zero the sums and the log
+        self.reset()
+        self.rollout(n_episodes * longest)
+        torch.cuda.synchronize(self.device)
+        done = m["episodes_done"].cpu().numpy()
+        if done.min() < n_episodes:
+            raise RanEnvError(f"an env finished only {int(done.min())} of {n_episodes} episodes: per-env max_steps longer than assumed")
+        log = m["episode_log"][:, :n_episodes].cpu().numpy()
+        return {name: log[:, :, k].copy() for k, name in enumerate(self.METRIC_NAMES)}
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -123,6 +123,50 @@ def test_rollout_through_episode_ends_equals_stepwise_autoreset(parts, random_ep
     a.close(); b.close()
 
 
+def test_evaluate_runs_whole_episodes_on_the_device_and_matches_the_oracle():
+    """evaluate(): reset + one rollout through n episodes per env; the per-episode sums against an oracle that plays the
+    same episodes (sequential episode numbers, equal lengths)."""
+    _need_gpu()
+    from oracle import pyoracle
+    B, L, n_ep, first, steps, n_eval = 8, 10, 12, 3, 20, 3
+    wl = _small_workload(B, steps)
+    env, tabs = wl.env, wl.tables
+    S, U, R = env.S, env.U, env.R
+    ep_no = np.arange(first, first + n_ep)
+    env.set_episode_table(scenario=ep_no % 6, se_base=(ep_no % 12) * L, se_len=L, se_offset=ep_no % L,
+                          trf_base=(ep_no % 6) * L, trf_len=L, trf_offset=(ep_no * 3) % L, first_episode=first)
+    start = first + np.arange(B) % n_ep
+    env.enable_autoreset(first, first + n_ep, episode_numbers=start)
+    env.enable_metrics(n_eval)
+    env.set_partitions(2)
+    res = env.evaluate(n_eval)
+    assert set(res) == set(env.METRIC_NAMES) and res["ttis"].shape == (B, n_eval) and np.all(res["ttis"] == steps)
+    cfg = pyoracle.make_cfg(S, U, R, env.G, env.Us, max_steps=steps)
+    se_host = wl.se_pool.transpose(1, 2).contiguous().cpu().numpy()
+    trf_host = wl.traffic_pool.cpu().numpy().astype(np.float64)
+    tab = env.episode_table
+    intra = np.full(S, 1, dtype=np.int32)
+    for b in range(B):
+        ep = int(start[b])
+        o = pyoracle.OracleEnv(cfg)                 # one object per env: the 10-TTI window survives a reset
+        for k in range(n_eval):
+            r = tab[ep - first]
+            o.set_scenario(tabs, int(r["scenario"]))
+            o.reset(se_host[int(r["se_base"] + r["se_offset"] % r["se_len"])])
+            exp = np.zeros(8)
+            for t in range(steps):
+                o.step(o.policy_mapf(), intra, se_host[int(r["se_base"] + (r["se_offset"] + t) % r["se_len"])],
+                       trf_host[int(r["trf_base"] + (r["trf_offset"] + t) % r["trf_len"])])
+                exp += _tti_metrics(o)
+            got = np.array([res[n][b, k] for n in env.METRIC_NAMES])
+            assert np.array_equal(got[[0, 2, 3, 6, 7]], exp[[0, 2, 3, 6, 7]]), (b, k, got, exp)
+            np.testing.assert_allclose(got[[1, 4, 5]], exp[[1, 4, 5]], rtol=0, atol=1e-8)
+            ep = ep + 1 if ep + 1 < first + n_ep else first
+    with pytest.raises(Exception, match="episode_slots"):
+        env.evaluate(n_eval + 1)
+    env.close()
+
+
 def test_metrics_api_errors():
     _need_gpu()
     from intent_radio_sched_multi_slice_amd._lib import RanEnvError
