@@ -766,7 +766,7 @@ DEVFN void step_body(const KP &p)
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
     if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
-#if RANENV_DIAG == 6 || RANENV_DIAG == 7     /* ablations: 6 = entry + stream only (ranges from the stored allocation, sums written out); 7 = no allocation */
+#if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8    /* ablations: 8 = no allocation and no obs tail; 10 = allocation + tail only; 6 = entry + stream only (ranges from the stored allocation, sums written out); 7 = no allocation */
     if (MODE == MODE_STEP) pre = true;
 #endif
     if (pre) {
@@ -805,7 +805,7 @@ DEVFN void step_body(const KP &p)
     };
     if (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
-#if RANENV_DIAG == 1
+#if RANENV_DIAG == 1 || RANENV_DIAG == 10
         my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
 #elif RANENV_DIAG == 2
         row_sums(se1, R, [=](int r) { return false; }, my_full, my_part, hook); my_part = (double)(us1 + uc1);
@@ -837,7 +837,7 @@ DEVFN void step_body(const KP &p)
 #endif
 #if RANENV_DIAG == 6
     if (false) {
-#elif RANENV_DIAG == 3 || RANENV_DIAG == 5
+#elif RANENV_DIAG == 3 || RANENV_DIAG == 5 || RANENV_DIAG == 10
     if (act && my_full < -1.0) {
 #else
     if (act) {
@@ -1010,7 +1010,7 @@ DEVFN void step_body(const KP &p)
     __syncthreads();
     RANENV_STAMP(6);
     do {
-#if RANENV_DIAG == 4 || RANENV_DIAG == 5 || RANENV_DIAG == 6   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
+#if RANENV_DIAG == 4 || RANENV_DIAG == 5 || RANENV_DIAG == 6 || RANENV_DIAG == 8   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
 #if RANENV_DIAG == 6
     if (true) {
 #else
@@ -1159,7 +1159,7 @@ DEVFN void step_body(const KP &p)
     // ---- (0') the next TTI's allocation, from the state this step leaves behind ----------------------
     bool late = false;
     if (MODE == MODE_STEP) late = p.scores == nullptr && (p.late == 2 || (p.late == 1 && (((unsigned)e * 0x9E3779B1u) >> 16 & 1u)));
-#if RANENV_DIAG == 6 || RANENV_DIAG == 7
+#if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8
     if (MODE == MODE_STEP) late = false;
 #endif
     if (late) {
