@@ -487,7 +487,7 @@ struct SharedCore {
     int si[GRP][8];               // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
     int pi[GRP][6];               // (metric, op) x 3
     int cnt[GRP][GRP + 4];        // RBs of each slot (padded like rows)
-    int flg[GRP][GRP + 4];        // buffer-not-empty flag of each slot
+    unsigned char flg[GRP][GRP + 4];   // buffer-not-empty flag of each slot (bytes: the struct stays below 12.5 KB, 12 workgroups' worth per CU)
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
 };
 
@@ -782,7 +782,8 @@ DEVFN void step_body(const KP &p)
     asm volatile("" ::: "memory");
     // zero the per-slice rows, park the tables
     for (int i = tid; i < GRP * (4 * GRP + 2); i += (int)blockDim.x) (&sh.rows[0][0])[i] = 0.0;
-    for (int i = tid; i < GRP * (GRP + 4); i += (int)blockDim.x) { (&sh.cnt[0][0])[i] = 0; (&sh.flg[0][0])[i] = 0; }
+    for (int i = tid; i < GRP * (GRP + 4); i += (int)blockDim.x) (&sh.cnt[0][0])[i] = 0;
+    for (int i = tid; i < GRP * (GRP + 4) / 4; i += (int)blockDim.x) reinterpret_cast<int *>(&sh.flg[0][0])[i] = 0;
     if (tid < S * 8) (&sh.si[0][0])[tid] = st_si;
     if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi;
     if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
