@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-stream", action="store_true",
+                    help="skip the one-launch-per-TTI comparison run (so that a rocprofv3 pass averages only the launches of "
+                         "the measured schedule)")
     args = ap.parse_args()
 
     import torch
@@ -213,7 +216,7 @@ def main():
     kms = env.profile_end()
     # ... and as one launch per TTI on one stream (what a caller that consumes every TTI's outputs gets)
     single = None
-    if parts > 1:
+    if parts > 1 and not args.no_single_stream:
         env.set_partitions(1)
         el1 = timed_steps(env.step, args.steps, torch.cuda.synchronize, barrier, max_over_ranks)
         single = {"value": batch * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,

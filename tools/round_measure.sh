@@ -21,7 +21,7 @@ python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE 4096 2 $out
 step pmc_sq 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -d $out/pmc_sq -o p --output-format csv -- python3 tools/profile_step.py 30
 step pmc_sq2 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT -d $out/pmc_sq2 -o p --output-format csv -- python3 tools/profile_step.py 30
 python3 tools/pmc_summary.py $out/pmc_sq $out/pmc_sq2 > $out/pmc_sq_summary.txt; cat $out/pmc_sq_summary.txt
-step bench_prof 400 rocprofv3 --kernel-trace --stats -d $out/prof -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline
+step bench_prof 400 rocprofv3 --kernel-trace --stats -d $out/prof -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --no-single-stream
 step bench 600 python3 bench.py
 step bench_driver 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
 step bench_single 300 python3 bench.py --partitions 1 --no-cpu-baseline
