@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 OBS_TOL = 1e-5
 REW_TOL = 1e-9
-N_CASES = 24
+N_CASES = int(__import__("os").environ.get("RANENV_FUZZ_CASES", "24"))   # more for a one-off soak: RANENV_FUZZ_CASES=400
 
 
 def _draw_case(k):
@@ -32,7 +32,8 @@ def _draw_case(k):
     low_se = int(rng.choice([0, 0, 3]))                  # every third UE has nearly no capacity
     how = ["external", "device_steps", "device_rollout"][k % 3]
     policy, intra = [(2, 1), (1, 0), (2, 2), (2, 0)][int(rng.integers(0, 4))]
-    return dict(S=S, U=U, R=R, G=G, Us=Us, D=D, load=load, low_se=low_se, how=how, policy=policy, intra=intra)
+    steps = int(rng.choice([12, 12, 30, 48]))            # the shortest latency budget is 20 TTIs: the longer runs expire packets
+    return dict(S=S, U=U, R=R, G=G, Us=Us, D=D, load=load, low_se=low_se, how=how, policy=policy, intra=intra, steps=steps)
 
 
 @pytest.mark.parametrize("k", range(N_CASES))
@@ -51,7 +52,7 @@ def test_fuzz_case_vs_oracle(k, build, monkeypatch):
     # the generator needs room for its smallest scenario
     n_sl_min = max(1, min(S, U // max(1, Us)) // 2)
     tabs = generate_scaled_scenarios(4, seed=40 + k, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=n_sl_min, min_ues=min_ues)
-    B, steps = 7, 12
+    B, steps = 7, c["steps"]
     scen = rng.integers(0, tabs.n_scenarios, B)
     se_pool = np.stack([se_tile(300 + k, t, U, R, low_se_every=c["low_se"]) for t in range(B * steps)])
     trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)]) * c["load"]
