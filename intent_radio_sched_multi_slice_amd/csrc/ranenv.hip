@@ -305,6 +305,9 @@ DEVFN RowPlan make_row_plan(int n)
                                   streams; with 8 loads in flight per lane the kernel fits 96 VGPRs = 5 waves per SIMD
                                   without spills; measured A/B in profiles/r02_ab_log.txt) */
 #endif
+#ifndef RANENV_COLD_ARGS
+#define RANENV_COLD_ARGS 1
+#endif
 #ifndef RANENV_METRICS
 #define RANENV_METRICS 1           /* 0 compiles the episode-metric sums out (A/B of their cost only) */
 #endif
@@ -491,6 +494,22 @@ struct SharedCore {
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
 };
 
+// Workgroup barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its global loads and
+// stores (__syncthreads() is a fence too: s_waitcnt vmcnt(0) before the barrier, i.e. the UE role's ~17 state stores would
+// have to be acknowledged before the obs role starts, and the SE loads requested ahead of the allocation would have to land
+// before its first exchange).  Nothing in the step kernel passes data between threads through global memory.
+#ifndef RANENV_LDS_BARRIER
+#define RANENV_LDS_BARRIER 1
+#endif
+DEVFN void wg_sync()
+{
+#if RANENV_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 DEVFN double *srow(SharedCore &sh, int s, int k) { return &sh.rows[s][k * GRP]; }
 
 // Role (0).  Called by every thread of the workgroup (it contains barriers); `have` = this thread's UE is
@@ -512,7 +531,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
     const bool has_pkts = have && !d_isclose(occ, 0.0);
     if (have) { r0[pos] = occ; r1[pos] = hm; sh.flg[sl][pos] = has_pkts ? 1 : 0; }
-    __syncthreads();
+    wg_sync();
 
     // ---- inter-slice: lane t < 16 of wave 0 is slice t ----------------------------------------------
     if (tid < WAVE) {            // the other waves go straight to the barrier below
@@ -591,7 +610,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             sh.rbs[s1] = mine; sh.off[s1] = incl - mine;
         }
     }
-    __syncthreads();
+    wg_sync();
 
     // ---- intra-slice: thread = UE; a slice's UEs exchange through its rows ---------------------------
     const int n = have ? sh.si[sl][2] : 0;
@@ -612,7 +631,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             avail = cap < backlog ? cap : backlog;
             r0[pos] = avail;                     // (the occupancy row was consumed by the inter-slice part)
         }
-        __syncthreads();
+        wg_sync();
         double num = avail;                                                            // MT: weights = avail
         if (choice == RANENV_INTRA_PF) {                                               // :584-602
             double snt = hm * (double)pk;
@@ -627,12 +646,12 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             num = starved ? 2.0 * max_avail : avail / snt;
         }
         if (have) r1[pos] = num;
-        __syncthreads();
+        wg_sync();
         const double wsum = np_sum16_lds(r1, n);
         use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;                 // :603-608
         my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
         if (have) r2[pos] = my_val;
-        __syncthreads();
+        wg_sync();
         unsigned gmv = 0;                        // which positions of the slice hold a non-zero value
 #pragma unroll
         for (int k = 0; k < 16; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
@@ -640,7 +659,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
         m_v = __popc(gmv);
         const int slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
         if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
-        __syncthreads();
+        wg_sync();
         if (use_round) {
             const double tot = np_sum16_lds(r3, m_v);
             prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
@@ -648,7 +667,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     }
     if (!all_rr) {
         if (have) sh.cnt[sl][pos] = prop;
-        __syncthreads();
+        wg_sync();
     }
     int count = 0;
     if (use_round) {
@@ -677,9 +696,9 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
     }
-    if (!all_rr) __syncthreads();                                                  // every prop was read
+    if (!all_rr) wg_sync();                                                  // every prop was read
     if (have) sh.cnt[sl][pos] = count;
-    __syncthreads();
+    wg_sync();
     int before = 0;                                                                // :464-478 contiguous ranges
 #pragma unroll
     for (int k = 0; k < 16; k++) before += k < pos ? sh.cnt[sl][k] : 0;
@@ -705,6 +724,17 @@ DEVFN void step_body(const KP &p)
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
     };
     RANENV_STAMP(0);
+#if RANENV_COLD_ARGS
+    // The kernel's argument block, read in place: a field that only a late role needs is fetched there (one scalar load)
+    // instead of sitting in -- or being spilled from -- SGPRs since kernel entry.  (The laundering keeps the compiler from
+    // merging these loads with the by-value copy it loads up front.)
+    typedef const __attribute__((address_space(4))) KP *kp_const_t;
+    kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kc));
+#define COLD(f) (kc->f)
+#else
+#define COLD(f) (p.f)
+#endif
     ranenv_episode ep = p.episodes[e];
     ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
     ep.se_len = uni(ep.se_len); ep.trf_len = uni(ep.trf_len);
@@ -788,7 +818,7 @@ DEVFN void step_body(const KP &p)
     if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi;
     if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
     if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
-    __syncthreads();
+    wg_sync();
     RANENV_STAMP(1);
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
@@ -823,7 +853,7 @@ DEVFN void step_body(const KP &p)
     rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
 #endif
     RANENV_STAMP(3);
-    __syncthreads();        // every thread is done with the allocation's use of the per-slice rows
+    wg_sync();        // every thread is done with the allocation's use of the per-slice rows
     RANENV_STAMP(4);
 
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
@@ -861,15 +891,15 @@ DEVFN void step_body(const KP &p)
                 traffic = 0.0;
                 if (slc >= 0 && sh.si[slc][1] != 0 && sh.sf[slc][1] > 0.0) {
                     unsigned rnd[4];
-                    philox4x32_10((unsigned)(p.env_id_base + e), (unsigned)episode_no, (unsigned)t, (unsigned)u,
-                                  (unsigned)p.trf_seed, (unsigned)(p.trf_seed >> 32), rnd);
+                    philox4x32_10((unsigned)(COLD(env_id_base) + e), (unsigned)episode_no, (unsigned)t, (unsigned)u,
+                                  (unsigned)COLD(trf_seed), (unsigned)(COLD(trf_seed) >> 32), rnd);
                     const size_t row = (size_t)sc * S + slc;
-                    const int k = poisson_draw(p.pois_cdf + row * 256, p.pois_guide + row * 64,
+                    const int k = poisson_draw(COLD(pois_cdf) + row * 256, COLD(pois_guide) + row * 64,
                                                ((unsigned long long)rnd[1] << 32) | rnd[0]);
                     traffic = (double)k * 1e6;
                 }
             }
-            pkt_thr = (int)((se_part * p.bw_per_rb) / psz);
+            pkt_thr = (int)((se_part * COLD(bw_per_rb)) / psz);
             pkt_in = (int)(traffic / psz);
             const int L = p.L;
             // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of (arrival TTI,
@@ -919,7 +949,7 @@ DEVFN void step_body(const KP &p)
         ST_front(p)[su] = front; ST_front_rem(p)[su] = front_rem; ST_fifo(p)[su] = fifo;
         ST_win_sent(p)[su] = win_sent; ST_win_dropped(p)[su] = win_drop;
         ST_pkt_effective_thr(p)[su] = (int32_t)sent; ST_dropped_pkts(p)[su] = (int32_t)dropped;
-        if (!(p.flags & RANENV_F_NO_RAW_OUTPUT)) {
+        if (!(COLD(flags) & RANENV_F_NO_RAW_OUTPUT)) {
             ST_pkt_incoming(p)[su] = (int32_t)pkt_in; ST_pkt_throughputs(p)[su] = (int32_t)pkt_thr;
         }
         sent_u = sent; drop_u = dropped;
@@ -946,7 +976,7 @@ DEVFN void step_body(const KP &p)
             for (int k = 0; k < 3; k++) { pm[k] = sh.pi[slc][2 * k]; po[k] = sh.pi[slc][2 * k + 1]; pv[k] = sh.pf[slc][k]; }
         }
         if (slc >= 0 && has_req) {
-            const double o = p.over;
+            const double o = COLD(over);
             bool dec[3] = {false, false, false};
             double val[3] = {1.0, 1.0, 1.0};
             int opm[3] = {0, 0, 0};
@@ -994,21 +1024,21 @@ DEVFN void step_body(const KP &p)
             srow(sh, slc, 0)[ue_pos] = dres[0]; srow(sh, slc, 1)[ue_pos] = dres[1]; srow(sh, slc, 2)[ue_pos] = dres[2];
             srow(sh, slc, 3)[ue_pos] = se_mean_new;
             sh.cnt[slc][ue_pos] = rb_count;
-            if (p.obs_intra && ue_pos < Us) {                                          // per-UE entries (:186-200)
-                float *oa = p.obs_intra + ((size_t)e * S + slc) * W;
+            if (COLD(obs_intra) && ue_pos < Us) {                                          // per-UE entries (:186-200)
+                float *oa = COLD(obs_intra) + ((size_t)e * S + slc) * W;
                 oa[9 + ue_pos] = (float)occ_new;
-                oa[9 + Us + ue_pos] = (float)(se_mean_new / p.norm_se);
+                oa[9 + Us + ue_pos] = (float)(se_mean_new / COLD(norm_se));
             }
         }
     }
-    if (MODE != MODE_RESET && (RANENV_METRICS && p.acc != nullptr)) {
+    if (MODE != MODE_RESET && (RANENV_METRICS && COLD(acc) != nullptr)) {
         // episode metrics: packet totals of the env, one add per wave (integers in doubles: exact in any order)
         const double ws = wave_sum_f64((double)sent_u), wd = wave_sum_f64((double)drop_u);
-        if ((tid & (WAVE - 1)) == 0) { acc_add(p.acc + (size_t)e * 8 + 6, ws); acc_add(p.acc + (size_t)e * 8 + 7, wd); }
+        if ((tid & (WAVE - 1)) == 0) { acc_add(COLD(acc) + (size_t)e * 8 + 6, ws); acc_add(COLD(acc) + (size_t)e * 8 + 7, wd); }
     }
     if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
     RANENV_STAMP(5);
-    __syncthreads();
+    wg_sync();
     RANENV_STAMP(6);
     do {
 #if RANENV_DIAG == 4 || RANENV_DIAG == 5 || RANENV_DIAG == 6 || RANENV_DIAG == 8   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
@@ -1065,14 +1095,14 @@ DEVFN void step_body(const KP &p)
         const double se_slice = n > 0 ? np_sum16_lds(srow(sh, s, 3), n) / (double)n : 0.0;   // :146-157
         const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
-        const float tr = (float)(traffic_req / p.norm_traffic), nu = (float)((double)n / p.norm_ues);
-        if (p.obs_inter) {                                                         // :160-173
-            float *oi = p.obs_inter + ((size_t)e * S + spos) * 10;
+        const float tr = (float)(traffic_req / COLD(norm_traffic)), nu = (float)((double)n / COLD(norm_ues));
+        if (COLD(obs_inter)) {                                                         // :160-173
+            float *oi = COLD(obs_inter) + ((size_t)e * S + spos) * 10;
             oi[0] = o0; oi[1] = o1; oi[2] = o2; oi[3] = a0; oi[4] = a1; oi[5] = a2;
-            oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)(se_slice / p.norm_se);
+            oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)(se_slice / COLD(norm_se));
         }
-        if (p.obs_intra) {
-            float *oa = p.obs_intra + ((size_t)e * S + s) * W;
+        if (COLD(obs_intra)) {
+            float *oa = COLD(obs_intra) + ((size_t)e * S + s) * W;
             oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
             oa[6] = (float)((double)rbs_s / (double)R); oa[7] = tr; oa[8] = nu;
             for (int k = n; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
@@ -1083,7 +1113,7 @@ DEVFN void step_body(const KP &p)
         for (int m = 0; m < 3; m++) {
             if (am[m] > 0.0) { r = (cnt == 0 || sv[m] < r) ? sv[m] : r; cnt++; }
         }
-        if (p.reward) p.reward[(size_t)e * (S + 1) + s + 1] = cnt > 0 ? r : 0.0;
+        if (COLD(reward)) COLD(reward)[(size_t)e * (S + 1) + s + 1] = cnt > 0 ? r : 0.0;
         if (MODE == MODE_RESET) {
             ST_mask_inter(p)[(size_t)e * S + s] = (int8_t)active;
             for (int k = 0; k < Us; k++) ST_mask_intra(p)[((size_t)e * S + s) * Us + k] = k < n ? 1 : 0;
@@ -1114,7 +1144,7 @@ DEVFN void step_body(const KP &p)
     // episode metrics: distance to fulfilment = sum of the negative slice drifts (entries beyond S are 0), all slices and
     // priority slices (priority is 0 or 1), as a fixed tree over the 16 lanes
     double dist = 0.0, prio_dist = 0.0;
-    if (MODE != MODE_RESET && (RANENV_METRICS && p.acc != nullptr)) {
+    if (MODE != MODE_RESET && (RANENV_METRICS && COLD(acc) != nullptr)) {
         dist = row16_sum_f64(fmin(my_ao, 0.0)); prio_dist = row16_sum_f64(fmin(my_ao * my_pr, 0.0));
     }
     const bool my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
@@ -1127,12 +1157,12 @@ DEVFN void step_body(const KP &p)
     if (tid == 0) {
         double rew = np_sum16_lds(xr[2], m_sel) / (double)m_sel;
         if (mode_sel == 1) rew -= 1.0;
-        if (p.reward) p.reward[(size_t)e * (S + 1)] = rew;
+        if (COLD(reward)) COLD(reward)[(size_t)e * (S + 1)] = rew;
         // Episode metrics (ranenv_enable_metrics): running sums of what the paper's evaluation reads per TTI
         // (results/gen_results.py:874-1022: slices in violation, distance to fulfilment, all slices / priority slices
         // only), of the inter-slice reward and of the packet totals.  One writer per env and TTI; fire-and-forget adds.
-        if ((RANENV_METRICS && p.acc != nullptr)) {
-            double *a = p.acc + (size_t)e * 8;
+        if ((RANENV_METRICS && COLD(acc) != nullptr)) {
+            double *a = COLD(acc) + (size_t)e * 8;
             if (MODE == MODE_RESET) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) a[k] = 0.0;
@@ -1151,8 +1181,8 @@ DEVFN void step_body(const KP &p)
             ST_se_pos(p)[e] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
             ST_trf_pos(p)[e] = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
         }
-        const int max_steps_e = p.max_steps_env ? p.max_steps_env[e] : p.max_steps;
-        if (p.done) p.done[e] = (MODE != MODE_RESET && step_new >= max_steps_e) ? 1 : 0;
+        const int max_steps_e = COLD(max_steps_env) ? COLD(max_steps_env)[e] : COLD(max_steps);
+        if (COLD(done)) COLD(done)[e] = (MODE != MODE_RESET && step_new >= max_steps_e) ? 1 : 0;
     }
     } while (0);
     RANENV_STAMP(7);
@@ -1164,7 +1194,7 @@ DEVFN void step_body(const KP &p)
     if (MODE == MODE_STEP) late = false;
 #endif
     if (late) {
-        __syncthreads();                     // (3) is done with the per-slice rows
+        wg_sync();                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
         alloc_front(p, sh, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
                     ns, nc, ST_next_scores(p));
@@ -1173,6 +1203,7 @@ DEVFN void step_body(const KP &p)
     if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
     RANENV_STAMP(8);
 }
+#undef COLD
 
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
 // 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 8 SE loads in flight per lane -- occupancy hides more latency

@@ -6,7 +6,10 @@ import torch
 from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
 config = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else None
-wl, _ = make_bench_workload(config, torch.device("cuda", 0), batch=batch)
+kw = {}
+if os.environ.get("RANENV_TRACES"):        # pool size: traces x trace_len tiles of 54 KB (small pools stay in L2 / MALL)
+    kw = dict(n_traces=int(os.environ["RANENV_TRACES"]), trace_len=int(os.environ.get("RANENV_TRACE_LEN", "200")))
+wl, _ = make_bench_workload(config, torch.device("cuda", 0), batch=batch, **kw)
 env = wl.env
 if os.environ.get("RANENV_METRICS") == "1":
     env.enable_metrics(0)
