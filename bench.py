@@ -220,6 +220,7 @@ def main():
         env.set_partitions(1)
         el1 = timed_steps(env.step, args.steps, torch.cuda.synchronize, barrier, max_over_ranks)
         single = {"value": batch * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
+                  "roofline_frac": batch * env.algorithmic_bytes_per_env_step() / (el1 / args.steps) / (HBM_PEAK_GBS * 1e9),
                   "launch": "one launch of the step kernel per TTI on one stream (env.step() in a loop)"}
 
     if rank == 0:
