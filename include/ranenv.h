@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 5
+#define RANENV_ABI_VERSION 6
 
 enum {
     RANENV_OK = 0,
@@ -57,6 +57,7 @@ enum {
 
 enum { RANENV_POLICY_EXTERNAL = 0, RANENV_POLICY_MARR = 1, RANENV_POLICY_MAPF = 2 };
 enum { RANENV_INTRA_RR = 0, RANENV_INTRA_PF = 1, RANENV_INTRA_MT = 2, RANENV_INTRA_PER_SLICE = 255 };
+enum { RANENV_SE_STREAM = 0, RANENV_SE_GATHER = 1 };
 enum { RANENV_METRIC_THROUGHPUT = 0, RANENV_METRIC_RELIABILITY = 1, RANENV_METRIC_LATENCY = 2 };
 enum { RANENV_OP_GE = 0, RANENV_OP_LE = 1, RANENV_OP_EQ = 2, RANENV_OP_GT = 3, RANENV_OP_LT = 4 };
 
@@ -203,6 +204,35 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       const double *dev_traffic_bits, const float *dev_se_tiles,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
+
+/* The same TTI for the envs [env_first, env_first + env_count) only, enqueued on `stream` and nothing else: no batch
+ * partitions, no joins.  All array arguments are the whole-batch arrays of ranenv_step (indexed by env).  This is the
+ * building block for a learner in the loop (the reference trains PPO through env.step, simu.py:555-566, with 10
+ * concurrent env runners, agents/ray_agent.py:296-300): step two halves of the batch alternately on two streams, and
+ * while the policy consumes one half's observations the other half's TTI occupies the GPU.  Ordering between a range's
+ * launches and the producer of its scores / consumer of its outputs is the caller's (events), as with any stream. */
+int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count,
+                      const double *dev_inter_scores, const uint8_t *dev_intra_choice,
+                      const double *dev_traffic_bits, const float *dev_se_tiles,
+                      float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
+                      void *stream);
+
+/* How steps and resets read SE tiles replayed from the bound pool.
+ *   RANENV_SE_STREAM (default)  every TTI streams the env's whole U x R tile: per UE the sum over all RBs (its mean is
+ *                               what the observation, PF / MT and MAPF consume: agents/ib_sched.py:110-116,146-157,
+ *                               agents/common.py:567-573,648-654, agents/mapf.py:75-90) and the sum over its allocated RBs.
+ *   RANENV_SE_GATHER            the per-UE mean over all RBs is a function of the tile alone -- exogenous, identical
+ *                               whatever the agent does (results/gen_results.py:1587-1635) -- so it is computed once per
+ *                               pooled tile ([tile][U] float64, numpy's pairwise order: bit-identical to the streamed
+ *                               value); a TTI then reads that row and, from a UE-major copy of the pool, only the RBs
+ *                               each UE was allocated (R elements per env instead of U x R).  Results are bit-identical.
+ *                               The call builds both sidecars for the pool bound now (handle-owned: n_tiles * U * (8 +
+ *                               4 * roundup(R, 8)) bytes); call it again after changing the pool's contents;
+ *                               ranenv_bind_se_pool falls back to STREAM.  Steps with explicit dev_se_tiles and
+ *                               ranenv_step_dense keep streaming. */
+int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream);
+/* Diagnostic: the gather mode's sidecars: row_mean [n_tiles][U] float64, ue_major [n_tiles][U][row_floats] float32. */
+int ranenv_get_se_sidecars(ranenv_handle h, double **dev_row_mean, float **dev_ue_major, int32_t *row_floats);
 
 /* Per-launch timing: between ranenv_profile_begin and ranenv_profile_end every launch of the step kernel carries its
  * dispatch's own start / stop timestamps (hipExtLaunchKernel events, valid with further launches queued behind it).

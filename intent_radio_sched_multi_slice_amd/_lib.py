@@ -11,10 +11,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranenv_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
 INTRA_RR, INTRA_PF, INTRA_MT, INTRA_PER_SLICE = 0, 1, 2, 255
 F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK = 0x1, 0x2, 0x4
+SE_STREAM, SE_GATHER = 0, 1
 
 EXPORTS = (
     "ranenv_last_error", "ranenv_abi_version", "ranenv_create", "ranenv_destroy",
@@ -24,6 +25,7 @@ EXPORTS = (
     "ranenv_launch_info", "ranenv_se_from_power", "ranenv_bind_head_outputs", "ranenv_set_slice_usecase",
     "ranenv_set_traffic_generator", "ranenv_set_max_steps", "ranenv_set_episode_table", "ranenv_set_autoreset",
     "ranenv_autoreset", "ranenv_get_poisson_tables", "ranenv_set_partitions", "ranenv_rollout", "ranenv_enable_metrics", "ranenv_get_metrics",
+    "ranenv_step_range", "ranenv_set_se_mode", "ranenv_get_se_sidecars",
 )
 
 
@@ -105,6 +107,9 @@ def load() -> C.CDLL:
     lib.ranenv_set_policy.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.ranenv_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ranenv_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+    lib.ranenv_step_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9
+    lib.ranenv_set_se_mode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.ranenv_get_se_sidecars.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
     lib.ranenv_set_partitions.argtypes = [C.c_void_p, C.c_int32]
     lib.ranenv_rollout.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
     lib.ranenv_enable_metrics.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]

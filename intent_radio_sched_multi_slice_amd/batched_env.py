@@ -17,6 +17,7 @@ gymnasium-style surface, batched (reference: ``env.reset`` / ``env.step`` simu.p
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -24,10 +25,10 @@ import torch
 
 from . import _lib
 from ._lib import (F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK, INTRA_MT, INTRA_PER_SLICE, INTRA_PF, INTRA_RR,
-                   POLICY_EXTERNAL, POLICY_MAPF, POLICY_MARR, RanEnvError)
+                   POLICY_EXTERNAL, POLICY_MAPF, POLICY_MARR, SE_GATHER, SE_STREAM, RanEnvError)
 from .scenario import MAX_AGE_CAP_DEFAULT, ScenarioTables
 
-_TORCH_DT = {"i1": torch.int8, "i4": torch.int32, "i8": torch.int64, "f8": torch.float64}
+_TORCH_DT = {"i1": torch.int8, "i4": torch.int32, "i8": torch.int64, "f8": torch.float64, "f4": torch.float32}
 
 
 class _DevArray:
@@ -97,6 +98,8 @@ class BatchedRanEnv:
         self._recorder = None
         self._autoreset = False
         self.term_obs_inter = self.term_obs_intra = self.term_head_obs = None
+        self.se_mode = "stream"
+        self._ranges = None          # set_ranges(): [(lo, hi, stream, done_event)] for step_async / step_wait
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -156,6 +159,31 @@ class BatchedRanEnv:
         self._keep["se_pool"] = se_pool
         self._check(self._lib.ranenv_bind_se_pool(self._h, _ptr(se_pool), se_pool.shape[0], self.R * self.U),
                     "ranenv_bind_se_pool")
+        self.se_mode = "stream"
+        if os.environ.get("RANENV_SE_MODE") == "gather":       # experiment / test knob, like RANENV_SMALL_BATCH and RANENV_LATE
+            self.set_se_mode("gather")
+
+    def set_se_mode(self, mode: str):
+        """``"stream"`` (default): every TTI streams the env's whole U x R tile.  ``"gather"``: the per-UE mean over all
+        RBs -- all that the observation, PF / MT and MAPF read of a tile (agents/ib_sched.py:110-116,146-157,
+        agents/common.py:567-573,648-654), a function of the tile alone -- is computed once per pooled tile, and a TTI reads
+        that row plus, from a UE-major copy of the pool, only the RBs each UE was allocated.  Bit-identical results; the two
+        sidecars (n_tiles * U * (8 + 4 * roundup(R, 8)) bytes) are built here for the pool bound now."""
+        if mode not in ("stream", "gather"):
+            raise RanEnvError("SE mode must be 'stream' or 'gather'")
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_set_se_mode(self._h, SE_GATHER if mode == "gather" else SE_STREAM, self._stream()),
+                        "ranenv_set_se_mode")
+        self.se_mode = mode
+
+    def se_sidecars(self) -> Dict[str, torch.Tensor]:
+        """Diagnostic: the gather mode's sidecars, zero copy: ``row_mean`` float64 [tiles, U], ``ue_major`` float32
+        [tiles, U, roundup(R, 8)]."""
+        mean, um, rp = C.c_void_p(), C.c_void_p(), C.c_int32()
+        self._check(self._lib.ranenv_get_se_sidecars(self._h, C.byref(mean), C.byref(um), C.byref(rp)), "ranenv_get_se_sidecars")
+        n = self._keep["se_pool"].shape[0]
+        return {"row_mean": torch.as_tensor(_DevArray(mean.value, (n, self.U), "f8", self), device=self.device),
+                "ue_major": torch.as_tensor(_DevArray(um.value, (n, self.U, rp.value), "f4", self), device=self.device)}
 
     def bind_traffic_pool(self, traffic_pool: torch.Tensor):
         """int32 [rows, U] offered bits per UE and TTI (traffics/mult_slice.py:26-32)."""
@@ -332,6 +360,54 @@ class BatchedRanEnv:
             self._after_step(se, ic)
         return self._obs(), self.reward, self.done
 
+    # -- a learner in the loop: ranges of the batch stepped alternately on their own streams -------------------------
+    def set_ranges(self, n_ranges: int = 2):
+        """Cut the batch into ``n_ranges`` contiguous ranges, each with its own HIP stream, for ``step_async`` /
+        ``step_wait``: while the policy consumes one range's observations, the other ranges' TTIs occupy the GPU (the
+        reference trains through env.step with 10 concurrent env runners, simu.py:555-566, agents/ray_agent.py:296-300)."""
+        if n_ranges < 1 or n_ranges > self.B:
+            raise RanEnvError("n_ranges must be in [1, batch]")
+        base, rem = divmod(self.B, n_ranges)
+        lo, self._ranges = 0, []
+        with torch.cuda.device(self.device):
+            for k in range(n_ranges):
+                hi = lo + base + (1 if k < rem else 0)
+                self._ranges.append((lo, hi, torch.cuda.Stream(self.device), torch.cuda.Event()))
+                lo = hi
+        return [(lo, hi) for lo, hi, _, _ in self._ranges]
+
+    def step_async(self, k: int, inter_scores=None, intra_choice=None, traffic_bits=None, se_tiles=None):
+        """Enqueue one TTI of range ``k`` on that range's stream, ordered behind what the caller's current stream holds
+        now (the kernels that produced the scores).  The arguments are whole-batch tensors ([B, ...], already on the
+        device: nothing is converted here); only range k's rows are read and written.  Returns at once; pair with
+        ``step_wait(k)``."""
+        if self._ranges is None:
+            raise RanEnvError("step_async needs set_ranges() first")
+        if self._recorder is not None or self._autoreset:
+            raise RanEnvError("step_async does not run the recorder / auto-reset hooks: use step()")
+        lo, hi, stream, done = self._ranges[k]
+        for name, x, dt in (("inter_scores", inter_scores, torch.float64), ("intra_choice", intra_choice, torch.uint8),
+                            ("traffic_bits", traffic_bits, torch.float64), ("se_tiles", se_tiles, torch.float32)):
+            if x is not None and not (isinstance(x, torch.Tensor) and x.device == self.device and x.dtype == dt
+                                      and x.is_contiguous() and x.shape[0] == self.B):
+                raise RanEnvError(f"step_async: {name} must be a contiguous {dt} tensor [B, ...] on {self.device}")
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+        st = self._lib.ranenv_step_range(self._h, lo, hi - lo, _ptr(inter_scores), _ptr(intra_choice), _ptr(traffic_bits),
+                                         _ptr(se_tiles), *self._p_out, C.c_void_p(stream.cuda_stream))
+        if st != 0:
+            self._check(st, "ranenv_step_range")
+        done.record(stream)
+        for x in (inter_scores, intra_choice, traffic_bits, se_tiles):     # the caching allocator must not recycle them early
+            if x is not None:
+                x.record_stream(stream)
+
+    def step_wait(self, k: int):
+        """Order the caller's current stream behind range ``k``'s last ``step_async`` (no host sync) and return views of
+        that range's rows: ({"obs_inter", "obs_intra"}, reward, done)."""
+        lo, hi, _, done = self._ranges[k]
+        torch.cuda.current_stream(self.device).wait_event(done)
+        return ({"obs_inter": self.obs_inter[lo:hi], "obs_intra": self.obs_intra[lo:hi]}, self.reward[lo:hi], self.done[lo:hi])
+
     def step_dense(self, sched_decision, traffic_bits=None, se_tiles=None):
         """One TTI with a caller-made dense sched_decision [B,U,R] (any agent's action_format)."""
         sd = self._dev(sched_decision, torch.uint8, (self.B, self.U, self.R), "sched_decision")
@@ -492,6 +568,11 @@ class BatchedRanEnv:
         self._check(self._lib.ranenv_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)), "ranenv_launch_info")
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
 
-    def algorithmic_bytes_per_env_step(self) -> int:
-        """4*U*R + 180*U + S*(85 + 8*Us) + 4."""
-        return 4 * self.U * self.R + 180 * self.U + self.S * (85 + 8 * self.Us) + 4
+    def algorithmic_bytes_per_env_step(self, se_mode: Optional[str] = None) -> int:
+        """4*U*R + 180*U + S*(85 + 8*Us) + 4 for the streaming step.  The gather mode replaces the
+        tile term 4*U*R by what it reads of a tile: the R allocated elements (every RB belongs to one UE) and the per-UE
+        mean row of the sidecar, 4*R + 8*U."""
+        rest = 180 * self.U + self.S * (85 + 8 * self.Us) + 4
+        if (se_mode or self.se_mode) == "gather":
+            return 4 * self.R + 8 * self.U + rest
+        return 4 * self.U * self.R + rest

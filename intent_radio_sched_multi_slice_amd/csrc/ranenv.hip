@@ -138,7 +138,9 @@ struct KP {
     Tables tab;
     State st;
     const ranenv_episode *episodes;
-    const float *se_pool; long long se_stride;
+    const float *se_pool; long long se_stride;   // RB-major pool (streaming kernels); the UE-major copy for the gather kernels
+    const double *se_mean_pool;                  // gather kernels: [tile][U] mean SE over the RBs of every pooled tile (sidecar)
+    int se_rp;                                   // gather kernels: floats per UE row of the UE-major copy (R rounded up to 8)
     const int32_t *trf_pool;
     // counter-based traffic (ranenv_set_traffic_generator): Poisson draws keyed (seed; env id, episode, step, UE)
     int trf_gen; int env_id_base; unsigned long long trf_seed;
@@ -324,21 +326,23 @@ struct SeStream {
     __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
     int voff, row_bytes;
 
+    int last_row;                  // byte offset of the tile's last row
     DEVFN void load(float (&dst)[8], int r0)
     {
-        // rows past the tile (the padding of the last, partial group) fall outside the descriptor's
-        // num_records: the buffer load returns 0 for them, no clamp needed
+        // The scalar offset of a buffer load takes no part in the descriptor's range check: rows past the tile (the
+        // padding of the last, partial group, never summed) are clamped to the last row instead (scalar min).
         int soff = r0 * row_bytes;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+            const int so = soff < last_row ? soff : last_row;
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
             soff += row_bytes;
         }
     }
     DEVFN void init(const float *tile, int U, int u, int R)
     {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
-        voff = u * 4; row_bytes = U * 4;
+        voff = u * 4; row_bytes = U * 4; last_row = (R - 1) * U * 4;
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
@@ -422,6 +426,83 @@ DEVFN void row_sums(SeStream<SE_NQ> &st, int R, InFn in, double &full, double &p
     }
     if (pl.n_leaves == 1) { full = lf; part = lg; return; }
     full = lf + rf; part = lg + rg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE gather (ranenv_set_se_mode GATHER): the masked sum alone, from a UE-major copy of the tile.
+// Every consumer of a tile except UEs.step reads only np.mean over all RBs per UE (agents/ib_sched.py:110-116,146-157,
+// agents/common.py:567-573,648-654): a function of the tile alone, exogenous like the tile (results/gen_results.py:1587-1635
+// checks that), so it is computed once per pooled tile (se_mean_pool) instead of once per env and TTI.  What is left per TTI
+// is sum_r sched[u,r] * SE[u,r]: each RB belongs to one UE, so an env touches R elements, not U x R.
+// Lane u owns [s, s + c) of row u (element r at byte offset row + r * 4, rows padded to a multiple of 8 floats) and walks
+// the aligned 8-groups its range touches.  The result is, bit for bit, what row_sums gives for `part`: numpy's order puts
+// element r into accumulator (r - leaf start) mod 8 of its leaf, an element outside the range adds +0.0 there (x + 0.0 == x
+// exactly), so groups without an element of the range can be skipped; the accumulator tree, the sequential tail and the
+// folding of the leaves are the same expressions as in row_sums.
+// Loads: two 16-byte buffer loads per group with the whole offset in the VGPR (range-checked: a lane that has no group
+// left gets an offset past the descriptor and reads 0 without touching memory), two groups in flight per lane.
+// ---------------------------------------------------------------------------------------------
+DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, tile_bytes, 0x00020000);
+    constexpr int OOB = 0x7ffffff0;
+    const RowPlan pl = make_row_plan(R);
+    const int tail = R & 7;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    auto ld8 = [&](float (&q)[8], int off) {
+        const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, 0));
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    };
+    auto in = [=](int r) { return ((unsigned)r - s) < c; };
+    double lg = 0.0, rg = 0.0;
+    int base = 0;
+#pragma unroll 1
+    for (int k = 0; k < pl.n_leaves; k++) {                       // wave-uniform
+        const int len = (k == 0) * pl.len0 + (k == 1) * pl.len1 + (k == 2) * pl.len2 + (k == 3) * pl.len3;
+        const int end = base + (len & ~7);                        // first RB behind the leaf's full groups
+        const bool last = k == pl.n_leaves - 1;
+        const int lo = (int)s > base ? (int)s : base, hi = (int)(s + c) < end ? (int)(s + c) : end;
+        int g0 = 0, ng = 0;                                       // this lane's groups inside the leaf
+        if (lo < hi) { g0 = (lo - base) >> 3; ng = ((hi - 1 - base) >> 3) - g0 + 1; }
+        const int first = row_bytes_off + (base + g0 * 8) * 4;
+        float q0[8], q1[8];
+        ld8(q0, 0 < ng ? first : OOB);
+        ld8(q1, 1 < ng ? first + 32 : OOB);
+        double g[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) g[j] = 0.0;
+        auto consume = [&](const float (&x)[8], int r0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) g[j] = fma((double)x[j], in(r0 + j) ? 1.0 : 0.0, g[j]);
+        };
+#pragma unroll 1
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < ng) != 0; i += 2) {
+            // a lane past its last group consumes zeros at RBs outside its range: +0.0
+            consume(q0, base + (g0 + i) * 8);
+            ld8(q0, i + 2 < ng ? first + (i + 2) * 32 : OOB);
+            consume(q1, base + (g0 + i + 1) * 8);
+            ld8(q1, i + 3 < ng ? first + (i + 3) * 32 : OOB);
+        }
+        double gr = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+        if (last && tail > 0) {
+            // the row's last R mod 8 RBs, added one after the other behind the tree; few ranges reach them, and a wave
+            // none of whose lanes does skips the load (the adds would all be + 0.0)
+            const bool want_tail = (int)(s + c) > end && c > 0;
+            if (__builtin_amdgcn_ballot_w64(want_tail) != 0) {
+                ld8(q0, want_tail ? row_bytes_off + end * 4 : OOB);
+#pragma unroll
+                for (int j = 0; j < 7; j++)
+                    if (j < tail) gr = fma((double)q0[j], in(end + j) ? 1.0 : 0.0, gr);
+            }
+        }
+        const bool left = pl.lsplit ? (k < 2) : (k < 1);
+        const bool first_of_half = pl.lsplit ? (k == 0 || k == 2) : (k <= 1);
+        if (left) lg = first_of_half ? gr : lg + gr;
+        else      rg = first_of_half ? gr : rg + gr;
+        base += len;
+    }
+    return pl.n_leaves == 1 ? lg : lg + rg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -706,10 +787,13 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     rb_count = have ? count : 0;
 }
 
-// The kernel body, instantiated twice (see the two kernels behind it): NQ = groups of 8 SE loads in flight per lane.
-template <int MODE, int NQ>
+// The kernel body, instantiated per build (see the kernels behind it): NQ = groups of 8 SE loads in flight per lane;
+// GATHER = the SE gather mode (the tile's per-UE mean from the sidecar, the masked sum by gather_part from the UE-major
+// copy; p.se_pool / p.se_stride then describe that copy) instead of streaming the whole RB-major tile.
+template <int MODE, int NQ, bool GATHER>
 DEVFN void step_body(const KP &p)
 {
+    static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     __shared__ SharedCore sh;
     auto &xr = sh.xr;
     const int e = p.e0 + blockIdx.x;
@@ -753,8 +837,9 @@ DEVFN void step_body(const KP &p)
     if (clear_hist) hlen = 0;
     const int hlen_new = hlen < D ? hlen + 1 : D;
     const float *tile;
-    if (p.se_tiles != nullptr) tile = p.se_tiles + (size_t)e * U * R;
-    else tile = p.se_pool + (size_t)(ep.se_base + (long long)se_pos) * (size_t)p.se_stride;
+    const long long tile_no = ep.se_base + (long long)se_pos;
+    if (!GATHER && p.se_tiles != nullptr) tile = p.se_tiles + (size_t)e * U * R;
+    else tile = p.se_pool + (size_t)tile_no * (size_t)p.se_stride;
 
     // ---- loads, in the order they are needed: memory operations retire in issue order (vmcnt), so what the
     // allocation waits for (tables, UE state) is issued before the SE tile and does not queue behind it
@@ -787,6 +872,8 @@ DEVFN void step_body(const KP &p)
     rest_of_state();
 #endif
     if (MODE == MODE_STEP) sem_prev = ST_se_mean(p)[su];
+    double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
+    if (GATHER) sem_tile = p.se_mean_pool[(size_t)tile_no * U + u];
     // the scenario's slice tables, one element per thread (blockDim >= 8*S), parked in LDS below
     int st_si = 0, st_pi = 0; double st_pf = 0.0, st_sf = 0.0;
     if (tid < S * 8) st_si = TB_slice_i32(p)[(size_t)sc * S * 8 + tid];
@@ -807,8 +894,8 @@ DEVFN void step_body(const KP &p)
     }
     const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
-    SeStream<NQ> se1;
-    se1.init(tile, U, u, R);                       // lane = UE: one dword per RB
+    SeStream<GATHER ? 1 : NQ> se1;
+    if (!GATHER) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // zero the per-slice rows, park the tables
     for (int i = tid; i < GRP * (4 * GRP + 2); i += (int)blockDim.x) (&sh.rows[0][0])[i] = 0.0;
@@ -834,7 +921,9 @@ DEVFN void step_body(const KP &p)
         rest_of_state();
 #endif
     };
-    if (MODE == MODE_STEP) {
+    if constexpr (GATHER) {
+        if (MODE == MODE_STEP) my_part = gather_part(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
+    } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1 || RANENV_DIAG == 10
         my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
@@ -843,7 +932,7 @@ DEVFN void step_body(const KP &p)
 #else
         row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part, hook);
 #endif
-    } else if (MODE == MODE_DENSE) {
+    } else if constexpr (MODE == MODE_DENSE) {
         const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
         row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part, hook);
     } else {
@@ -880,7 +969,7 @@ DEVFN void step_body(const KP &p)
                 if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
             }
         }
-        const double se_mean_new = my_full / (double)R, se_part = my_part;
+        const double se_mean_new = GATHER ? sem_tile : my_full / (double)R, se_part = my_part;
         int dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;     // all < 2^31 (host validates the packet counts)
         if (MODE != MODE_RESET) {
             const double psz = (double)pkt_size;
@@ -1218,11 +1307,44 @@ DEVFN void step_body(const KP &p)
 #define RANENV_CORE_ATTR
 #endif
 template <int MODE>
-__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p) { step_body<MODE, RANENV_SE_DEPTH>(p); }
+__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p) { step_body<MODE, RANENV_SE_DEPTH, false>(p); }
 template <int MODE>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
 {
-    step_body<MODE, RANENV_SE_DEPTH_SMALL>(p);
+    step_body<MODE, RANENV_SE_DEPTH_SMALL, false>(p);
+}
+// The SE gather build (ranenv_set_se_mode): no tile stream, so no queue registers; one build for every batch size.
+#ifndef RANENV_GATHER_WAVES_PER_EU
+#define RANENV_GATHER_WAVES_PER_EU 5
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_GATHER_WAVES_PER_EU, RANENV_GATHER_WAVES_PER_EU)))
+ranenv_core_kernel_gather(const KP p) { step_body<MODE, 1, true>(p); }
+
+// ---------------------------------------------------------------------------------------------
+// Sidecars of the SE pool for the gather mode, built once per bound pool (ranenv_set_se_mode):
+//   mean[tile][u]    = np.mean(SE[u, :]) in float64, numpy's pairwise order (row_sums' `full`, divided by R): bit for bit what
+//                      the streaming kernel derives from the tile every TTI
+//   um[tile][u][Rp]  = the tile UE-major, rows padded with zeros to Rp = R rounded up to 8 floats
+// One workgroup per tile, thread = UE for the means; the copy is a plain index transform (reads served by L2).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CORE_NT) ranenv_se_sidecar_kernel(const float *pool, long long stride, long long tile0, int U, int R, int Rp,
+                                                                    double *mean, float *um)
+{
+    const long long t = tile0 + blockIdx.x;
+    const float *tile = pool + (size_t)t * (size_t)stride;
+    const int tid = threadIdx.x;
+    const int u = tid < U ? tid : U - 1;
+    SeStream<4> se;
+    se.init(tile, U, u, R);
+    double full = 0.0, part = 0.0;
+    row_sums(se, R, [](int) { return false; }, full, part, []() {});
+    if (tid < U) mean[(size_t)t * U + tid] = full / (double)R;
+    float *out = um + (size_t)t * (size_t)U * Rp;
+    for (int i = tid; i < U * Rp; i += (int)blockDim.x) {
+        const int uu = i / Rp, r = i - uu * Rp;
+        out[i] = r < R ? tile[(size_t)r * U + uu] : 0.0f;
+    }
 }
 
 // =============================================================================================
@@ -1508,6 +1630,9 @@ struct ranenv {
     std::vector<double> slice_traffic;          // [NS][S] host copy (traffic generator tables)
     std::vector<int32_t> slice_has_req;
     int64_t se_tiles_n = 0, trf_rows_n = 0;   // extents of the bound pools (0 = none)
+    // SE gather mode (ranenv_set_se_mode): sidecars of the bound pool, owned by the handle
+    int se_mode = RANENV_SE_STREAM;
+    double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
     bool small_batch = false;                   // at most 8 workgroups per CU: the 128-VGPR build with the deeper SE queue
@@ -1616,6 +1741,14 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
 {
     kp.e0 = e0;
     const dim3 grid((unsigned)n), block((unsigned)h->nt);
+    // SE gather mode: tiles replayed from the pool are read through the sidecars; explicit per-step tiles and dense
+    // sched_decisions (whole rows are needed) keep the streaming kernel
+    bool gather = false;
+    if constexpr (MODE != MODE_DENSE) gather = h->se_mode == RANENV_SE_GATHER && kp.se_tiles == nullptr;
+    if (gather) {
+        kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
+        kp.se_mean_pool = h->d_se_mean; kp.se_rp = h->se_rp;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (h->prof_on) {                              // two more events from the pool
         while (h->prof_ev.size() < h->prof_used + 2) {
@@ -1627,7 +1760,12 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         ev0 = h->prof_ev[h->prof_used]; ev1 = h->prof_ev[h->prof_used + 1];
         h->prof_used += 2;
     }
-    if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
+    if (gather) {
+        if constexpr (MODE != MODE_DENSE) {
+            if (ev0) hipExtLaunchKernelGGL(ranenv_core_kernel_gather<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
+            else hipLaunchKernelGGL(ranenv_core_kernel_gather<MODE>, grid, block, 0, stream, kp);
+        }
+    } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
         if (h->small_batch) hipExtLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
         else hipExtLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
     } else {
@@ -1679,10 +1817,20 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
     return hipSuccess;
 }
 
+// What every launch of a call shares: the host's allocation generation, and whether the next TTI's allocation may be made
+// ahead (role 0').  It may only when nothing a later call passes can change it: with the intra-slice scheduler taken from
+// the step's own intra_choice argument (RANENV_INTRA_PER_SLICE) an allocation made at the end of TTI t would use TTI t's
+// choices for TTI t+1, so there every step allocates at its head and no stored allocation is consumed.
+void finalize_kp(ranenv_handle h, KP &kp)
+{
+    kp.alloc_gen = h->alloc_gen;
+    if (kp.fixed_intra == RANENV_INTRA_PER_SLICE) kp.late = 0;
+}
+
 template <int MODE>
 hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = true, bool join_out = true)
 {
-    kp.alloc_gen = h->alloc_gen;
+    finalize_kp(h, kp);
     return for_partitions(h, stream, join_in, join_out,
                           [&](int e0, int n, hipStream_t s) { return launch_range<MODE>(h, kp, e0, n, s); });
 }
@@ -1887,6 +2035,7 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
 int ranenv_bind_se_pool(ranenv_handle h, const float *dev_pool, int64_t n_tiles, int64_t tile_stride)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    h->se_mode = RANENV_SE_STREAM;             // the sidecars describe the pool they were built from
     if (dev_pool == nullptr) {
         h->kp.se_pool = nullptr; h->kp.se_stride = 0; h->se_tiles_n = 0;
         return RANENV_OK;
@@ -1994,6 +2143,76 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     return RANENV_OK;
 }
 
+int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count, const double *scores, const uint8_t *intra,
+                      const double *traffic_bits, const float *se_tiles, float *obs_inter, float *obs_intra, double *reward,
+                      uint8_t *done, void *stream)
+{
+    int rc = check_ready(h, se_tiles, traffic_bits, true);
+    if (rc != RANENV_OK) return rc;
+    if (env_first < 0 || env_count < 1 || (long long)env_first + env_count > h->cfg.batch)
+        return fail(h, RANENV_E_INVALID, "envs [%d,%d) outside the batch of %d", env_first, env_first + env_count, h->cfg.batch);
+    if (!scores && h->kp.policy == RANENV_POLICY_EXTERNAL) return fail(h, RANENV_E_STATE, "policy is EXTERNAL but no inter-slice scores were given");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    KP kp = h->kp;
+    kp.env_mask = nullptr; kp.se_tiles = se_tiles; kp.scores = scores; kp.intra = intra; kp.traffic_bits = traffic_bits;
+    kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
+    finalize_kp(h, kp);
+    hipError_t e = launch_range<MODE_STEP>(h, kp, env_first, env_count, (hipStream_t)stream);
+    if (e == hipSuccess && (h->cfg.flags & RANENV_F_SYNC_CHECK)) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "step launch (envs [%d,%d)): %s", env_first, env_first + env_count, hipGetErrorString(e));
+    return RANENV_OK;
+}
+
+int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (mode != RANENV_SE_STREAM && mode != RANENV_SE_GATHER) return fail(h, RANENV_E_INVALID, "unknown SE mode %d", mode);
+    if (mode == RANENV_SE_STREAM) { h->se_mode = RANENV_SE_STREAM; return RANENV_OK; }
+    if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "the SE gather mode needs a bound SE pool (ranenv_bind_se_pool)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int U = h->cfg.n_ues, R = h->cfg.n_rbs, Rp = (R + 7) & ~7;
+    const size_t nt = (size_t)h->se_tiles_n;
+    // (re)build the sidecars for the pool as it is now: older ones are released first
+    auto drop = [&](void *ptr) {
+        if (!ptr) return;
+        for (size_t i = 0; i < h->allocs.size(); i++) if (h->allocs[i] == ptr) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+        (void)hipFree(ptr);
+    };
+    HIP_TRY(h, hipDeviceSynchronize());
+    drop(h->d_se_mean); drop(h->d_se_um); h->d_se_mean = nullptr; h->d_se_um = nullptr;
+    void *pm = nullptr, *pu = nullptr;
+    hipError_t e = hipMalloc(&pm, nt * (size_t)U * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&pu, nt * (size_t)U * (size_t)Rp * sizeof(float));
+    if (e != hipSuccess) {
+        if (pm) (void)hipFree(pm);
+        return fail(h, RANENV_E_NOMEM, "SE gather sidecars (%zu tiles: %.2f GB): %s", nt,
+                    (double)(nt * (size_t)U * (8 + 4 * (size_t)Rp)) / 1e9, hipGetErrorString(e));
+    }
+    h->allocs.push_back(pm); h->allocs.push_back(pu);
+    h->d_se_mean = (double *)pm; h->d_se_um = (float *)pu; h->se_rp = Rp;
+    for (size_t t0 = 0; t0 < nt; t0 += 1u << 20) {              // grid.x stays far below its limit
+        const size_t n = nt - t0 < (1u << 20) ? nt - t0 : (1u << 20);
+        hipLaunchKernelGGL(ranenv_se_sidecar_kernel, dim3((unsigned)n), dim3((unsigned)h->nt), 0, stream, h->kp.se_pool,
+                           (long long)h->kp.se_stride, (long long)t0, U, R, Rp, h->d_se_mean, h->d_se_um);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "SE sidecar launch: %s", hipGetErrorString(e));
+    if (h->cfg.flags & RANENV_F_SYNC_CHECK) HIP_TRY(h, hipStreamSynchronize(stream));
+    h->se_mode = RANENV_SE_GATHER;
+    return RANENV_OK;
+}
+
+int ranenv_get_se_sidecars(ranenv_handle h, double **dev_row_mean, float **dev_ue_major, int32_t *row_floats)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (!h->d_se_mean) return fail(h, RANENV_E_STATE, "no SE sidecars (ranenv_set_se_mode GATHER builds them)");
+    if (dev_row_mean) *dev_row_mean = h->d_se_mean;
+    if (dev_ue_major) *dev_ue_major = h->d_se_um;
+    if (row_floats) *row_floats = h->se_rp;
+    return RANENV_OK;
+}
+
 int ranenv_profile_begin(ranenv_handle h)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
@@ -2053,7 +2272,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     hipStream_t stream = (hipStream_t)stream_;
-    kp.alloc_gen = h->alloc_gen;
+    finalize_kp(h, kp);
     // With auto-reset on, an env whose episode ends inside the rollout moves on to its next episode without the host:
     // the advance kernel + the step kernel in RESET mode follow that TTI's step on the partition's stream.  They are only
     // enqueued for TTIs at which some env of the partition finishes: the step counters are read once here and followed
@@ -2068,6 +2287,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
         HIP_TRY(h, hipMemcpy(steps.data(), ST_step_no(h->kp), sizeof(int32_t) * steps.size(), hipMemcpyDeviceToHost));
         adv = advance_args(h, done, obs_inter, obs_intra, nullptr, nullptr, nullptr);
         kpr.env_mask = h->d_ar_mask; kpr.reward = nullptr; kpr.done = nullptr;
+        kpr.head_reward = nullptr;               // the terminal transition's head rewards stay, like reward / done
     }
     const bool follow = h->ar_on;
     for (int i = 0; i < n_steps; i++) {
@@ -2228,6 +2448,7 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = nullptr; kp.done = nullptr;   // the step's rewards stay
+    kp.head_reward = nullptr;                    // ... those of the alternative heads too (head_obs gets the new episode's first observation)
     const hipError_t e = launch<MODE_RESET>(h, kp, stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "auto-reset launch: %s", hipGetErrorString(e));
     return RANENV_OK;

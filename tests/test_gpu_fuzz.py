@@ -37,11 +37,13 @@ def _draw_case(k):
 
 
 @pytest.mark.parametrize("k", range(N_CASES))
-@pytest.mark.parametrize("build", ["lean", "small"])
+@pytest.mark.parametrize("build", ["lean", "small", "gather"])
 def test_fuzz_case_vs_oracle(k, build, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if build == "lean" else "1")
+    if build == "gather":           # the SE gather mode: sidecars built at bind, tiles read through them
+        monkeypatch.setenv("RANENV_SE_MODE", "gather")
     from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     from oracle import pyoracle

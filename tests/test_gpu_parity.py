@@ -23,12 +23,15 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-@pytest.fixture(params=["lean", "small"])
+@pytest.fixture(params=["lean", "small", "gather"])
 def build(request, monkeypatch):
-    """The step kernel has two builds (96 VGPRs / 8 SE loads in flight for batches that fill the CUs, 128 VGPRs / 32 in
-    flight for small ones); ranenv_create picks by batch size.  Test batches are small, so the choice is forced here
-    (RANENV_SMALL_BATCH is read at create) and every case runs against both."""
+    """The streaming step kernel has two builds (96 VGPRs / 8 SE loads in flight for batches that fill the CUs, 128 VGPRs /
+    32 in flight for small ones); ranenv_create picks by batch size.  Test batches are small, so the choice is forced here
+    (RANENV_SMALL_BATCH is read at create) and every case runs against both -- and against the SE gather mode
+    (RANENV_SE_MODE=gather: BatchedRanEnv.bind_se_pool switches it on, pooled tiles are then read through the sidecars)."""
     monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if request.param == "lean" else "1")
+    if request.param == "gather":
+        monkeypatch.setenv("RANENV_SE_MODE", "gather")
     return request.param
 
 
@@ -65,16 +68,22 @@ def test_golden_traces(case, build):
     env.load_scenarios(tabs)
     env.set_policy(0, 255)
     k = 0
+    pooled = build == "gather"     # the gather mode reads pooled tiles: the episode's tiles become a trace of the pool
     for ep, idx in enumerate(fx["scen_ids"]):
         get_se = (lambda t: np.full((U, R), 2.0, dtype=np.float32)) if plumbing else \
             (lambda t: se_tile(seed + ep, t, U, R))
-        env.set_episodes(scenario=int(idx))
+        if pooled:
+            env.bind_se_pool(torch.as_tensor(np.stack([_rb_major(get_se(t)) for t in range(steps_per_ep)]), device=env.device))
+            assert env.se_mode == "gather"
+            env.set_episodes(scenario=int(idx), se_base=0, se_len=steps_per_ep)
+        else:
+            env.set_episodes(scenario=int(idx))
         se0 = np.broadcast_to(_rb_major(get_se(0)), (B, R, U))
-        obs = env.reset(se_tiles=se0)
+        obs = env.reset(se_tiles=None if pooled else se0)
         got = np.concatenate([obs["obs_inter"][1].cpu().numpy(), obs["obs_intra"][1].cpu().numpy().ravel()])
         np.testing.assert_allclose(got, fx["reset_obs"][ep], rtol=0, atol=OBS_TOL)
         for t in range(steps_per_ep):
-            se = np.broadcast_to(_rb_major(get_se(t)), (B, R, U))
+            se = None if pooled else np.broadcast_to(_rb_major(get_se(t)), (B, R, U))
             sc = np.broadcast_to(fx["scores"][k], (B, S))
             ic = np.broadcast_to(fx["intra"][k].astype(np.uint8), (B, S))
             tr = np.broadcast_to(fx["traffic"][k], (B, U))

@@ -1,0 +1,310 @@
+"""SE gather mode (ranenv_set_se_mode), range stepping for a learner in the loop (ranenv_step_range: step_async /
+step_wait), and the regressions of the round-2 advisor findings: head rewards at an auto-reset, device policy with a
+per-step intra-slice choice.  All through the C ABI, against the oracle; integers bit-exact, observations 1e-5, rewards 1e-9.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.common import poisson_traffic_rows
+from tests.synth import se_tile
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL, REW_TOL = 1e-5, 1e-9
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _rb_major(a):
+    return np.ascontiguousarray(np.swapaxes(a, -1, -2))
+
+
+@pytest.mark.parametrize("shape", [dict(U=7, R=5), dict(U=37, R=100), dict(U=100, R=135), dict(U=128, R=300),
+                                   dict(U=64, R=408), dict(U=256, R=64)])
+def test_gather_sidecars_are_numpy_means_and_the_transposed_pool(shape):
+    """row_mean[tile][u] must be np.mean(SE[u, :]) of the float32 tile in float64 -- numpy's pairwise order, every
+    shape of it -- bit for bit (the oracle's orc_np_sum is the checker); ue_major is the tile transposed, rows
+    zero-padded to a multiple of 8."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from oracle import pyoracle
+    U, R = shape["U"], shape["R"]
+    S, Us = 4, 4
+    n_tiles = 9
+    pool = np.stack([se_tile(11, t, U, R) for t in range(n_tiles)])          # [tiles, U, R]
+    env = BatchedRanEnv(batch=2, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=1, max_ues_slice=Us, n_scenarios=1, max_steps=4)
+    env.bind_se_pool(torch.as_tensor(_rb_major(pool), device=env.device))
+    env.set_se_mode("gather")
+    sc = env.se_sidecars()
+    mean, um = sc["row_mean"].cpu().numpy(), sc["ue_major"].cpu().numpy()
+    Rp = (R + 7) // 8 * 8
+    assert um.shape == (n_tiles, U, Rp)
+    assert np.array_equal(um[:, :, :R], pool) and not um[:, :, R:].any()
+    for t in range(n_tiles):
+        for u in range(U):
+            assert mean[t, u] == pyoracle.np_sum(pool[t, u].astype(np.float64)) / R, (t, u)
+    # numpy itself, where its pairwise blocking is the documented one (contiguous float64 rows)
+    np.testing.assert_array_equal(mean, pool.astype(np.float64).mean(axis=2))
+    env.close()
+
+
+def _bench_like(B, gather, seed=10, n_traces=16, trace_len=24, steps=1000):
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    wl = make_mult_slice_workload(B, torch.device("cuda", 0), n_scenarios=32, n_traces=n_traces, trace_len=trace_len,
+                                  seed=seed, max_steps=steps)
+    if gather:
+        wl.env.set_se_mode("gather")
+    return wl
+
+
+def test_gather_equals_stream_at_full_size():
+    """BASELINE configs[2] (B 4096, S 10 / U 100 / R 135, MAPF + PF) stepped 40 TTIs in both SE modes -- step by step and
+    as a rollout over 3 partitions: every state array, observation and reward must be bit-identical."""
+    _need_gpu()
+    B, T = 4096, 40
+    a, b, c = _bench_like(B, False), _bench_like(B, True), _bench_like(B, True)
+    assert (a.env.se_mode, b.env.se_mode) == ("stream", "gather")
+    a.env.reset(); b.env.reset(); c.env.reset()
+    assert torch.equal(a.env.obs_inter, b.env.obs_inter) and torch.equal(a.env.obs_intra, b.env.obs_intra)
+    for t in range(T):
+        a.env.step(); b.env.step()
+        if t in (0, 1, 9, T - 1):
+            for k, x in a.env.views().items():
+                assert torch.equal(x, b.env.views()[k]), (t, k)
+            assert torch.equal(a.env.obs_inter, b.env.obs_inter) and torch.equal(a.env.obs_intra, b.env.obs_intra), t
+            assert torch.equal(a.env.reward, b.env.reward), t
+    c.env.set_partitions(3)
+    c.env.rollout(T)
+    torch.cuda.synchronize()
+    for k, x in a.env.views().items():
+        assert torch.equal(x, c.env.views()[k]), k
+    assert torch.equal(a.env.obs_inter, c.env.obs_inter) and torch.equal(a.env.reward, c.env.reward)
+    # an allocation that hands one UE many RBs and others none did occur (ranges of 0 RBs and ranges across several 8-groups both walked)
+    cnt = a.env.views()["rb_count"]
+    assert int(cnt.max()) > 8 and int((cnt == 0).sum()) > 0
+    for w in (a, b, c):
+        w.env.close()
+
+
+def test_gather_mode_keeps_streaming_for_explicit_tiles_and_dense_steps():
+    """In gather mode a step with explicit se_tiles and a dense step still read whole rows (streaming kernel): same
+    results as an env in stream mode; rebinding a pool falls back to stream."""
+    _need_gpu()
+    B = 6
+    a, b = _bench_like(B, False, steps=8), _bench_like(B, True, steps=8)
+    U, R, S = a.env.U, a.env.R, a.env.S
+    rng = np.random.default_rng(3)
+    a.env.set_policy(0, 255); b.env.set_policy(0, 255)
+    a.env.reset(); b.env.reset()
+    for t in range(6):
+        sc = torch.as_tensor(rng.uniform(-1, 1, (B, S)), device=a.env.device)
+        ic = torch.as_tensor(rng.integers(0, 3, (B, S)).astype(np.uint8), device=a.env.device)
+        if t % 3 == 0:      # pooled tile
+            a.env.step(sc, ic); b.env.step(sc, ic)
+        elif t % 3 == 1:    # explicit tile
+            se = torch.as_tensor(np.stack([_rb_major(se_tile(77 + t, e, U, R)) for e in range(B)]), device=a.env.device)
+            a.env.step(sc, ic, se_tiles=se); b.env.step(sc, ic, se_tiles=se)
+        else:               # dense decision made from the pooled tile's allocation of the other env
+            st, cn = a.env.views()["rb_start"].cpu().numpy(), a.env.views()["rb_count"].cpu().numpy()
+            dense = np.zeros((B, U, R), dtype=np.uint8)
+            for e in range(B):
+                for u in range(U):
+                    dense[e, u, st[e, u]:st[e, u] + cn[e, u]] = 1
+            a.env.step_dense(dense); b.env.step_dense(dense)
+        for k, x in a.env.views().items():
+            assert torch.equal(x, b.env.views()[k]), (t, k)
+        assert torch.equal(a.env.obs_intra, b.env.obs_intra) and torch.equal(a.env.reward, b.env.reward), t
+    b.env.bind_se_pool(b.se_pool)
+    assert b.env.se_mode == "stream"
+    a.env.close(); b.env.close()
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_mode):
+    """A learner in the loop: the batch as two halves on two streams (set_ranges / step_async / step_wait).  The scores
+    of a half are produced on the caller's stream from that half's last observation (a stand-in policy: a function of
+    the observation, so any ordering slip between the streams changes the numbers), 30 TTIs, against the oracle."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    from oracle import pyoracle
+    S, U, R, G, Us, B, steps = 10, 100, 135, 1, 10, 48, 30
+    tabs = generate_scaled_scenarios(6, seed=4)
+    rng = np.random.default_rng(17)
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    trace_len, n_traces = 32, 5
+    se_pool = np.stack([se_tile(60 + i // trace_len, i % trace_len, U, R) for i in range(n_traces * trace_len)])
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, trace_len) for b in range(B)])
+    se_trace, se_off = rng.integers(0, n_traces, B), rng.integers(0, trace_len, B)
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+                        n_scenarios=tabs.n_scenarios, max_steps=steps)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(_rb_major(se_pool), device=env.device))
+    env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=scen, se_base=se_trace * trace_len, se_len=trace_len, se_offset=se_off,
+                     trf_base=np.arange(B) * trace_len, trf_len=trace_len)
+    env.set_policy(0, 1)                      # caller's inter-slice scores, PF inside the slices
+    if se_mode == "gather":
+        env.set_se_mode("gather")
+    ranges = env.set_ranges(2)
+    assert ranges == [(0, 24), (24, 48)]
+    cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+    oenvs = []
+    for b in range(B):
+        o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, int(scen[b]))
+        o.reset(se_pool[se_trace[b] * trace_len + se_off[b]]); oenvs.append(o)
+    env.reset()
+
+    def policy_dev(obs_inter):               # [n, S*10] float32 -> [n, S] float64 in [-1, 1], on the current stream
+        x = obs_inter.view(-1, S, 10).to(torch.float64)
+        return torch.tanh(x[:, :, 0] + 0.5 * x[:, :, 1] - x[:, :, 2] + 0.25 * x[:, :, 9])
+
+    def policy_host(o):                      # the same function on the oracle's observation (float32-rounded like the device's)
+        x = o["obs_inter"].astype(np.float32).astype(np.float64).reshape(S, 10)
+        return np.tanh(x[:, 0] + 0.5 * x[:, 1] - x[:, 2] + 0.25 * x[:, 9])
+
+    scores = torch.zeros((B, S), dtype=torch.float64, device=env.device)
+    ic = np.ones(S, dtype=np.int32)
+    # prime the pipeline: both halves get their first TTI from the reset observation
+    in_flight = [None, None]                  # the scores a half's TTI in flight was launched with (host copy: exact)
+    for k, (lo, hi) in enumerate(ranges):
+        scores[lo:hi] = policy_dev(env.obs_inter[lo:hi])
+        in_flight[k] = scores[lo:hi].cpu().numpy()
+        env.step_async(k, scores, None)       # intra-slice scheduler fixed by set_policy
+    host_obs = [o.obs() for o in oenvs]
+    for k, (lo, hi) in enumerate(ranges):
+        for j, b in enumerate(range(lo, hi)):
+            np.testing.assert_allclose(in_flight[k][j], policy_host(host_obs[b]), rtol=0, atol=1e-5)
+    t_of = [0, 0]
+    for it in range(2 * (steps - 1)):
+        k = it % 2
+        lo, hi = ranges[k]
+        obs, rew, done = env.step_wait(k)
+        # oracle: the TTI that was in flight for this half, with the very scores the device used
+        sc_host = in_flight[k]
+        for j, b in enumerate(range(lo, hi)):
+            o = oenvs[b]
+            tile = se_trace[b] * trace_len + (se_off[b] + t_of[k]) % trace_len
+            o.step(sc_host[j], ic, se_pool[tile], trf[b * trace_len + t_of[k] % trace_len])
+            host_obs[b] = o.obs()
+        t_of[k] += 1
+        # next TTI of this half: its scores from its new observation, on the caller's stream
+        scores[lo:hi] = policy_dev(obs["obs_inter"])
+        got_sc = in_flight[k] = scores[lo:hi].cpu().numpy()
+        g = {n: x[lo:hi].cpu().numpy() for n, x in env.views().items() if x.shape[0] == B}
+        goi, goa, grw = obs["obs_inter"].cpu().numpy(), obs["obs_intra"].cpu().numpy(), rew.cpu().numpy()
+        env.step_async(k, scores, None)
+        for j, b in enumerate(range(lo, hi)):
+            raw, oo = oenvs[b].raw(), host_obs[b]
+            for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                assert np.array_equal(g[name][j].astype(np.float64), raw[name]), (it, b, name)
+            np.testing.assert_allclose(goi[j], oo["obs_inter"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(goa[j], oo["obs_intra"], rtol=0, atol=OBS_TOL)
+            np.testing.assert_allclose(grw[j], oo["reward"], rtol=0, atol=REW_TOL)
+            np.testing.assert_allclose(got_sc[j], policy_host(oo), rtol=0, atol=1e-5)
+    for k in range(2):
+        env.step_wait(k)
+    torch.cuda.synchronize()
+    env.close()
+
+
+def test_step_range_argument_checks():
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd._lib import RanEnvError
+    wl = _bench_like(8, False, steps=4)
+    env = wl.env
+    with pytest.raises(RanEnvError, match="set_ranges"):
+        env.step_async(0)
+    env.set_ranges(2)
+    with pytest.raises(RanEnvError, match="contiguous"):
+        env.step_async(0, inter_scores=torch.zeros((4, env.S), dtype=torch.float64, device=env.device))
+    import ctypes as C
+    st = env._lib.ranenv_step_range(env._h, 6, 4, None, None, None, None, None, None, None, None, None)
+    assert st == -1 and b"outside the batch" in env._lib.ranenv_last_error(env._h)
+    env.close()
+
+
+def test_device_policy_with_a_random_intra_choice_every_step():
+    """ranenv_step(scores = NULL, intra_choice = X_t) with fixed_intra = PER_SLICE: MAPF scores on the device, the
+    caller picks every slice's scheduler anew every TTI.  An allocation made ahead at the end of TTI t would have used
+    X_t for TTI t+1."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    from oracle import pyoracle
+    S, U, R, G, Us, B, steps = 5, 25, 135, 5, 5, 32, 24
+    tabs = generate_scaled_scenarios(6, seed=3, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=3, min_ues=2)
+    rng = np.random.default_rng(5)
+    scen = rng.integers(0, tabs.n_scenarios, B)
+    se_pool = np.stack([se_tile(41, t, U, R) for t in range(B * steps)])
+    trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)])
+    for policy in (1, 2):
+        env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
+                            n_scenarios=tabs.n_scenarios, max_steps=steps)
+        env.load_scenarios(tabs)
+        env.bind_se_pool(torch.as_tensor(_rb_major(se_pool), device=env.device))
+        env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
+        env.set_episodes(scenario=scen, se_base=np.arange(B) * steps, se_len=steps, trf_base=np.arange(B) * steps, trf_len=steps)
+        env.set_policy(policy, 255)
+        cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
+        oenvs = []
+        for b in range(B):
+            o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
+        env.reset()
+        for t in range(steps):
+            ic = rng.integers(0, 3, (B, S)).astype(np.uint8)
+            obs, rew, done = env.step(None, ic)
+            g = {k: x.cpu().numpy() for k, x in env.views().items()}
+            for b, o in enumerate(oenvs):
+                sc = o.policy_marr() if policy == 1 else o.policy_mapf()
+                _, count, _ = o.action_format(sc, ic[b], want_dense=False)
+                assert np.array_equal(g["rb_count"][b], count), (policy, t, b)
+                o.step(sc, ic[b], se_pool[b * steps + t], trf[b * steps + t])
+                raw = o.raw()
+                for name in ("pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                    assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (policy, t, b, name)
+                np.testing.assert_allclose(rew[b].cpu().numpy(), o.obs()["reward"], rtol=0, atol=REW_TOL)
+        env.close()
+
+
+def test_head_reward_of_the_terminal_transition_survives_the_device_autoreset():
+    """HeadVecEnv with device auto-reset must hand SB3 the reward of the terminal transition, not the reward of the
+    freshly reset state: same rewards (and dones) as the host-side reset path at every step, including `done` steps."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.adapters import HeadVecEnv
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+
+    def make():
+        wl = make_mult_slice_workload(8, torch.device("cuda", 0), policy=2, intra=1, n_scenarios=6, n_traces=12, trace_len=10,
+                                      n_slices=5, n_ues=25, n_rbs=135, rbs_per_rbg=5, max_ues_slice=10, max_steps=6)
+        ep_no = np.arange(0, 6)
+        wl.env.set_episode_table(scenario=ep_no % 6, se_base=ep_no * 10, se_len=10, trf_base=(ep_no % 6) * 10, trf_len=10)
+        start = np.arange(8) % 6
+        t = wl.env.episode_table[start]
+        wl.env.set_episodes(scenario=t["scenario"], se_base=t["se_base"], se_len=t["se_len"], se_offset=t["se_offset"],
+                            trf_base=t["trf_base"], trf_len=t["trf_len"], trf_offset=t["trf_offset"])
+        return wl, start
+    for reward in ("twc", "colran"):
+        wa, start = make()
+        wb, _ = make()
+        uc = np.tile(np.array([1, 2, 1, 3, 0], dtype=np.int32), (6, 1))
+        va, vb = HeadVecEnv(wa.env, reward=reward, slice_usecase=uc), HeadVecEnv(wb.env, reward=reward, slice_usecase=uc)
+        va.enable_device_autoreset(0, 6, episode_numbers=start)
+        va.reset(); vb.reset()
+        rng = np.random.default_rng(2)
+        for t in range(6):                       # one episode: the host path cannot follow the device's episode advance
+            act = rng.uniform(-1, 1, (8, wa.env.S))
+            oa, ra, da, ia = va.step(act)
+            ob, rb, db, ib = vb.step(act)
+            assert np.array_equal(da, db), t
+            np.testing.assert_array_equal(ra, rb)
+            if da.any():
+                assert np.abs(ra).sum() > 0
+                for i in np.nonzero(da)[0]:
+                    np.testing.assert_array_equal(ia[i]["terminal_observation"], ib[i]["terminal_observation"])
+        va.close(); vb.close()
