@@ -6,19 +6,29 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one TTI of every env of the batch (device MAPF policy -> inter-slice split -> PF
-intra-slice -> UEs.step -> intent observation and reward).  The K timed steps are enqueued with
-``ranenv_rollout`` over 3 batch partitions (ranges of independent envs, each stepped by its own launch on its own HIP
-stream, joined with the caller's stream before the first and after the last TTI); the same K steps as one launch per
-TTI on one stream are timed right after and reported beside it (``single_stream``).  Workload at N=1: BASELINE.json configs[2], the configuration the north_star's
-throughput target is quoted on (mult_slice, 10 slices / 100 UEs / 135 RBGs, batch 4096, PF
-intra-slice + ib_sched intent reward); with N GPUs every rank steps its own 4096 envs (weak
-scaling; N=8 is configs[3], batch 32768 sharded 8x).  Inputs (scenario, SE and traffic pools)
-are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+intra-slice -> UEs.step -> intent observation and reward).  Workload at N=1: BASELINE.json configs[2], the
+configuration the north_star's throughput target is quoted on (mult_slice, 10 slices / 100 UEs / 135 RBGs, batch 4096,
+PF intra-slice + ib_sched intent reward); with N GPUs every rank steps its own 4096 envs (weak scaling; N=8 is
+configs[3], batch 32768 sharded 8x).  Inputs (scenario, SE and traffic pools) are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+
+What is timed, each as blocks of EXACTLY K steps between barrier + device sync on both sides (MAX over ranks); a block
+is repeated until ~20 ms of stepping are sampled, the median block is reported (`repeats`, min / max beside it):
+
+  value / roofline   the headline, SURVEY 8(d)'s streaming step kernel: `ranenv_rollout` (the K TTIs of the device
+                     policy enqueued in one call) over 3 batch partitions on 3 HIP streams
+  single_stream      the same K TTIs as env.step() in a loop: one launch per TTI on one stream
+  pipelined_step     a learner in the loop: external inter-slice scores produced from each half's last observation
+                     on that half's own stream, two half-batches stepped alternately (set_ranges / range_stream /
+                     step_async / step_wait)
+  se_gather          the headline schedule in the SE gather mode (ranenv_set_se_mode: per-tile mean-SE sidecar + reads
+                     of the allocated RBs only), with its own byte model and bound
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,6 +39,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_SIMD, CLOCK_HZ, VALU_CYCLES = 256 * 4, 2.4e9, 4.0   # 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction issues over >= 4 cycles
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_collect.py)
+SAMPLE_S = 0.020                                      # stepping time sampled per timed variant
 
 
 def usable_cores() -> int:
@@ -97,35 +110,58 @@ def timed_steps(step_fn, n_steps: int, sync_fn, barrier_fn, max_over_ranks_fn):
     return max_over_ranks_fn(time.perf_counter() - t0)
 
 
-def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed, launch_ms, n_launches, parts, traffic, metrics,
-               workload_extra="", single_stream=None):
-    """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region (the whole TTI of the
-    whole batch); the step kernel's per-launch duration (the dispatch's own timestamps, from the same K steps repeated
-    with timing on) is listed beside it -- with partitions `parts` launches of batch/parts envs overlap."""
+def timed_blocks(block_fn, sync_fn, barrier_fn, max_over_ranks_fn, sample_s: float = SAMPLE_S, max_repeats: int = 64):
+    """block_fn() enqueues EXACTLY the K steps of one block.  One block is timed (bracketed as in timed_steps), then the
+    block is repeated max(1, ceil(sample_s / that time)) times, each repeat bracketed and timed on its own; returns the
+    list of per-block times (every rank derives the same repeat count from the MAX-over-ranks time)."""
+    first = timed_steps(block_fn, 1, sync_fn, barrier_fn, max_over_ranks_fn)
+    repeats = max(1, min(max_repeats, int(math.ceil(sample_s / max(first, 1e-9)))))
+    return [timed_steps(block_fn, 1, sync_fn, barrier_fn, max_over_ranks_fn) for _ in range(repeats)]
+
+
+def block_stats(times, env_steps_per_block: float, steps: int):
+    """median / min / max of the per-block times as env-steps/s and ms per step."""
+    med = float(np.median(times))
+    return {"value": env_steps_per_block / med, "ms_per_step": med / steps * 1e3, "repeats": len(times),
+            "value_min": env_steps_per_block / max(times), "value_max": env_steps_per_block / min(times)}
+
+
+def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, launch_ms, n_launches, parts, pmc, metrics,
+               workload_extra="", extras=None):
+    """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region (the median block: the
+    whole TTI of the whole batch); the step kernel's per-launch duration (the dispatch's own timestamps, from the same
+    K steps repeated with timing on) is listed beside it -- with partitions `parts` launches of batch/parts envs overlap."""
     S, U, R = env_sizes
-    total_env_steps = batch * world * args.steps
-    value = total_env_steps / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
+    st = block_stats(times, batch * world * args.steps, args.steps)
+    ms_per_step = st["ms_per_step"]
     alg_bytes = alg_bytes_env_step * batch                       # per TTI of one rank's batch
     achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9            # per-GPU GB/s on the wall clock
     launch_bytes = alg_bytes / parts
     launch_gbs = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    traffic = (pmc or {}).get("stream")
+    schedule = (f"ranenv_rollout: the K TTIs of the device policy enqueued in one call, batch stepped as {parts} partitions on "
+                f"{parts} HIP streams (one launch of the step kernel per partition and TTI), no host between TTIs") if parts > 1 else \
+        "one launch of the step kernel per TTI on one stream"
     line = {
-        "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling",
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling"
+                  + (" [device-policy rollout over batch partitions; step-by-step and learner-in-the-loop schedules beside it]"
+                     if parts > 1 else ""),
+        "value": st["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "repeats": st["repeats"], "value_min": st["value_min"], "value_max": st["value_max"],
+        "timing": f"blocks of exactly {args.steps} steps, each between barrier + device sync (MAX over ranks); value = median of "
+                  f"{st['repeats']} blocks",
         "config": {"workload": f"BASELINE.json configs[{args.config}]: {label}; batch {batch} per GPU; SE replayed from "
                                f"an HBM pool of {args.traces}x{args.trace_len} float32 tiles{workload_extra}",
                    "batch_per_gpu": batch, "global_batch": batch * world, "n_slices": S, "n_ues": U,
                    "n_rbs": R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only",
-                   "launch": (f"ranenv_rollout: the K TTIs enqueued in one call, batch stepped as {parts} partitions on {parts} "
-                              "HIP streams (one launch of the step kernel per partition and TTI)") if parts > 1 else
-                             "one launch of the step kernel per TTI on one stream"},
+                   "launch": schedule, "se_mode": "stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "clock": "wall clock of the timed region (same as value)",
                      "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
-                     "traffic_source": traffic.get("source") if traffic else None,
+                     "traffic_source": (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, one launch per "
+                                        f"TTI on one stream, {traffic.get('date', 'undated')}; not measured in this run)") if traffic else None,
                      "kernel": "ranenv_core_kernel<STEP> (one TTI = %d concurrent launch(es) of it)" % parts,
                      "algorithmic_bytes_per_env_step": alg_bytes_env_step,
                      "algorithmic_bytes_per_tti": alg_bytes,
@@ -137,9 +173,32 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, elapsed
                                                    "right after the timed region under the same schedule"}},
         "metrics": metrics,
     }
-    if single_stream is not None:
-        line["single_stream"] = single_stream
+    line.update(extras or {})
     return line
+
+
+def gather_block(env, batch, world, steps, times, launch_ms, n_launches, parts, pmc):
+    """The `se_gather` object: the headline schedule in the SE gather mode, against the gather mode's own bytes and --
+    it is not HBM-bound -- against the VALU issue rate."""
+    st = block_stats(times, batch * world * steps, steps)
+    b_env = env.algorithmic_bytes_per_env_step("gather")
+    t = st["ms_per_step"] * 1e-3
+    hbm_frac = b_env * batch / t / (HBM_PEAK_GBS * 1e9)
+    out = dict(st)
+    out.update({"bytes_per_env_step": b_env,
+                "bytes_model": "4*R (allocated RBs, each read once) + 8*U (sidecar row of per-UE mean SE) + 180*U + S*(85+8*Us) + 4",
+                "hbm_frac": hbm_frac, "kernel": "ranenv_core_kernel_gather<STEP>",
+                "dominant_kernel_ms": launch_ms, "n_launches": n_launches, "concurrent_launches": parts})
+    g = (pmc or {}).get("gather")
+    if g and g.get("valu_insts_per_launch"):
+        issue_s = g["valu_insts_per_launch"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ)
+        out.update({"valu_insts_per_tti": g["valu_insts_per_launch"], "issue_bound_s": issue_s, "issue_frac": issue_s / t,
+                    "issue_model": f"SQ_INSTS_VALU per TTI x {VALU_CYCLES:g} cycles / ({N_SIMD} SIMDs x {CLOCK_HZ / 1e9:g} GHz)",
+                    "traffic": g.get("hbm_bytes_per_launch"), "pmc_source": f"{PMC_FILE} ({g.get('date', 'undated')}; not measured in this run)"})
+        out["bound"], out["frac"] = ("valu-issue", out["issue_frac"]) if out["issue_frac"] >= hbm_frac else ("hbm", hbm_frac)
+    else:
+        out["bound"], out["frac"] = "hbm", hbm_frac
+    return out
 
 
 def main():
@@ -154,18 +213,22 @@ def main():
     ap.add_argument("--traces", type=int, default=200)
     ap.add_argument("--trace-len", type=int, default=1000,
                     help="TTIs per channel trace (1000 = a whole episode: no env ever replays a tile; the pool is "
-                         "traces x trace_len x 54 KB = 10.8 GB)")
+                         "traces x trace_len x 54 KB = 10.8 GB, + 11.0 GB of sidecars for the se_gather variant)")
     ap.add_argument("--traffic", choices=("pool", "philox"), default="pool",
                     help="offered traffic: replayed Poisson pool (parity mode) or the device counter-based generator")
     ap.add_argument("--partitions", type=int, default=None,
                     help="batch partitions on their own HIP streams (default: 3 on one GPU, 2 per rank in a multi-GPU run, "
                          "1 when the batch does not fill the CUs)")
+    ap.add_argument("--ranges", type=int, default=2, help="ranges of the batch the pipelined_step variant alternates between")
     ap.add_argument("--cpu-envs", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=6000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true",
-                    help="skip the one-launch-per-TTI comparison run (so that a rocprofv3 pass averages only the launches of "
-                         "the measured schedule)")
+                    help="skip the comparison schedules (single_stream, pipelined_step), so that a rocprofv3 pass averages only "
+                         "the launches of the measured schedule")
+    ap.add_argument("--no-gather", action="store_true", help="skip the se_gather variant (and its sidecar build)")
+    ap.add_argument("--only-gather", action="store_true", help="profiling aid: run the se_gather variant only (the line's value "
+                                                                "is then the gather mode's, labelled so)")
     args = ap.parse_args()
 
     import torch
@@ -186,17 +249,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    wl, label = make_bench_workload(args.config, device, batch=args.batch, n_traces=args.traces,
-                                    trace_len=args.trace_len, rank=rank, traffic=args.traffic)
+    try:
+        wl, label = make_bench_workload(args.config, device, batch=args.batch, n_traces=args.traces,
+                                        trace_len=args.trace_len, rank=rank, traffic=args.traffic)
+    except (torch.OutOfMemoryError, _lib.RanEnvError) as e:       # the first run on a new box must not die on plumbing
+        raise SystemExit(f"rank {rank}: building the workload failed ({e}).  The SE pool is traces x trace_len x 54 KB "
+                         f"(= {args.traces * args.trace_len * 54e3 / 1e9:.1f} GB here, generated on the GPU in 110 MB bursts) plus "
+                         "~1.8 GB of env state at batch 4096: pass a smaller --traces / --trace-len if this GPU is shared.")
     env = wl.env
     batch = env.B
     # partitions: 3 measured best on one GPU (caller's stream + 2); a process has 4 hardware queues and RCCL wants some
     # of them in a multi-rank run, so there 2 (caller's stream + 1; within 2 % of 3 on one GPU)
     parts = args.partitions if args.partitions is not None else ((3 if world == 1 else 2) if batch >= 2048 else 1)
-    env.set_partitions(parts)
-    env.reset()
-    env.rollout(max(1, args.warmup))
-    gather_metrics(local_metrics(env.reward, env.views(), env.done, 1))   # warm torch's reduction kernels / RCCL
 
     def max_over_ranks(x):
         if world == 1:
@@ -206,41 +270,121 @@ def main():
         return float(t.item())
 
     barrier = dist.barrier if world > 1 else (lambda: None)
-    # EXACTLY K steps: one ranenv_rollout call enqueues the K TTIs of every env
-    elapsed = timed_steps(lambda: env.rollout(args.steps), 1, torch.cuda.synchronize, barrier, max_over_ranks)
-    # metrics: the only collective, once per reporting interval, outside the timed K steps
-    gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, args.steps))
-    # the same K steps again with the dispatch timestamps of every launch
-    env.profile_begin()
-    env.rollout(args.steps)
-    kms = env.profile_end()
-    # ... and as one launch per TTI on one stream (what a caller that consumes every TTI's outputs gets)
-    single = None
-    if parts > 1 and not args.no_single_stream:
-        env.set_partitions(1)
-        el1 = timed_steps(env.step, args.steps, torch.cuda.synchronize, barrier, max_over_ranks)
-        single = {"value": batch * world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
-                  "roofline_frac": batch * env.algorithmic_bytes_per_env_step() / (el1 / args.steps) / (HBM_PEAK_GBS * 1e9),
-                  "launch": "one launch of the step kernel per TTI on one stream (env.step() in a loop)"}
+    sync = torch.cuda.synchronize
+    K = args.steps
+    extras = {}
+
+    def rollout_variant():
+        """warm-up, the timed blocks of one ranenv_rollout(K) each, then the same K steps with per-launch timestamps."""
+        env.set_partitions(parts)
+        env.reset()
+        env.rollout(max(1, args.warmup))
+        times = timed_blocks(lambda: env.rollout(K), sync, barrier, max_over_ranks)
+        env.profile_begin()
+        env.rollout(K)
+        kms = env.profile_end()
+        return times, kms
+
+    times = kms = None
+    gathered = None
+    if not args.only_gather:
+        gather_metrics(local_metrics(env.reward, env.views(), env.done, 1))   # warm torch's reduction kernels / RCCL
+        times, kms = rollout_variant()
+        # metrics: the only collective, once per reporting interval, outside the timed K steps ...
+        gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
+        if world > 1:     # ... and one variant with it inside: K steps + the all_gather of the interval's accumulators
+            tg = timed_blocks(lambda: (env.rollout(K), gather_metrics(local_metrics(env.reward, env.views(), env.done, K))),
+                              sync, barrier, max_over_ranks)
+            extras["with_metrics_gather"] = dict(block_stats(tg, batch * world * K, K),
+                                                 note="the K-step block plus one all_gather of the 8 float64 accumulators per rank")
+        if not args.no_single_stream:
+            alg = env.algorithmic_bytes_per_env_step("stream")
+            if parts > 1:      # one launch per TTI on one stream (what a caller that joins every TTI gets)
+                env.set_partitions(1)
+                t1 = timed_blocks(lambda: [env.step() for _ in range(K)], sync, barrier, max_over_ranks)
+                s1 = block_stats(t1, batch * world * K, K)
+                s1.update({"roofline_frac": batch * alg / (s1["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                           "launch": "one launch of the step kernel per TTI on one stream (env.step() in a loop)"})
+                extras["single_stream"] = s1
+            # a learner in the loop: scores from the caller's stream, two halves alternating on their own streams
+            env.set_partitions(1)
+            env.set_policy(_lib.POLICY_EXTERNAL, wl.intra)
+            nr = args.ranges
+            ranges = env.set_ranges(nr)
+            scores = torch.zeros((batch, env.S), dtype=torch.float64, device=device)
+            S = env.S
+            # stand-in policy: a function of the range's last inter-slice observation, one small kernel on the caller's
+            # stream (tanh of every slice's first drift entry, float32 in, float64 scores out)
+            p_in = [env.obs_inter[lo:hi].view(hi - lo, S, 10)[:, :, 0] for lo, hi in ranges]
+            p_out = [scores[lo:hi] for lo, hi in ranges]
+
+            def policy(k):
+                torch.tanh(p_in[k], out=p_out[k])
+
+            rs = [env.range_stream(k) for k in range(nr)]
+            main_stream = torch.cuda.current_stream(device)
+
+            def pipelined_block():      # every range an in-order chain TTI -> policy -> TTI on its own stream
+                for _ in range(K):
+                    for k in range(nr):
+                        torch.cuda.set_stream(rs[k])
+                        env.step_wait(k)
+                        policy(k)
+                        env.step_async(k, scores)
+                torch.cuda.set_stream(main_stream)
+            env.reset()
+            sync()
+            for k in range(nr):
+                torch.cuda.set_stream(rs[k])
+                policy(k); env.step_async(k, scores)
+            torch.cuda.set_stream(main_stream)
+            pipelined_block()
+            tp = timed_blocks(pipelined_block, sync, barrier, max_over_ranks)
+            sp = block_stats(tp, batch * world * K, K)
+            sp.update({"roofline_frac": batch * alg / (sp["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                       "launch": f"external inter-slice scores (a torch op computed from each range's last observation on that range's "
+                                 f"own stream), PF intra-slice; the batch as {nr} ranges, each an in-order chain TTI -> policy -> TTI "
+                                 "enqueued by ranenv_step_part on the range's stream (set_ranges / range_stream / step_wait / "
+                                 "step_async), the host alternating between the ranges; a step = one TTI of every range"})
+            extras["pipelined_step"] = sp
+            for k in range(nr):
+                env.step_wait(k)
+            sync()
+            env.set_policy(wl.policy, wl.intra)
+
+    pmc = None
+    if rank == 0 and os.path.exists(os.path.join(REPO, PMC_FILE)):
+        try:
+            pj = json.load(open(os.path.join(REPO, PMC_FILE)))
+            if pj.get("batch") == batch and pj.get("config") == args.config:
+                pmc = {m: dict(pj[m], date=pj.get("date")) for m in ("stream", "gather") if m in pj}
+        except Exception:
+            pmc = None
+
+    if not args.no_gather:
+        try:
+            env.set_se_mode("gather")
+        except _lib.RanEnvError as e:
+            extras["se_gather"] = {"skipped": f"sidecars not built: {e}"}
+        else:
+            tg, kg = rollout_variant()
+            if rank == 0:
+                extras["se_gather"] = gather_block(env, batch, world, K, tg, kg["step"], kg["n_launches"], parts, pmc)
+            if args.only_gather:
+                times, kms = tg, kg
+                gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
+            env.set_se_mode("stream")
 
     if rank == 0:
-        traffic = None
-        tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                if tj.get("batch") == batch and tj.get("config") == args.config:
-                    traffic = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
-                               "source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of an earlier run of this "
-                                         f"workload, {tj.get('date', 'undated')}; not measured in this run)"}
-            except Exception:
-                traffic = None
-        line = build_line(args, world, batch, label, (env.S, env.U, env.R), env.algorithmic_bytes_per_env_step(),
-                          elapsed, kms["step"], kms["n_launches"], parts, traffic, summarize(gathered.cpu()),
+        line = build_line(args, world, batch, label, (env.S, env.U, env.R),
+                          env.algorithmic_bytes_per_env_step("gather" if args.only_gather else "stream"),
+                          times, kms["step"], kms["n_launches"], parts, pmc, summarize(gathered.cpu()),
                           workload_extra=(", Poisson traffic pool" if args.traffic == "pool"
                                           else ", Poisson traffic drawn on the device (Philox4x32-10)"),
-                          single_stream=single)
-        if world == 1 and not args.no_cpu_baseline:
+                          extras=extras)
+        if args.only_gather:
+            line["config"]["se_mode"] = "gather (profiling aid: value and roofline are the gather mode's, not the headline)"
+        if world == 1 and not args.no_cpu_baseline and not args.only_gather:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_envs, args.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:

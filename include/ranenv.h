@@ -217,6 +217,29 @@ int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
 
+/* The same for partition `part` of ranenv_set_partitions, with the stream plumbing done here (one call per launch, no
+ * event objects on the caller's side): ranenv_step_part orders the partition's own stream behind what `stream` holds
+ * now, enqueues the partition's TTI there and returns; ranenv_wait_part orders `stream` behind that TTI (no host
+ * sync).  Pattern for two partitions A, B and a policy running on `stream`:
+ *     step_part(A); step_part(B);  loop { wait_part(A); scores_A = policy(obs_A); step_part(A);   -- B's TTI is running
+ *                                         wait_part(B); scores_B = policy(obs_B); step_part(B); } -- A's TTI is running
+ * The caller must leave partition k's rows of the input arrays alone between step_part(k) and wait_part(k).
+ * ranenv_get_partition returns a partition's env range.
+ * Every dependency between two streams is a signal between two hardware queues (measured here: ~37 us from the end of a
+ * partition's TTI, through a small policy kernel on another stream, to the start of its next TTI).  A learner that runs
+ * partition k's policy on partition k's own stream (ranenv_get_part_stream: a hipStream_t owned by the handle, valid until
+ * the next ranenv_set_partitions / ranenv_destroy) and passes that stream to step_part / wait_part needs none: both calls
+ * then rely on stream order alone, and each partition is an independent in-order chain TTI -> policy -> TTI on its own
+ * queue -- the reference's concurrent env runners (agents/ray_agent.py:296-300), one per stream. */
+int ranenv_step_part(ranenv_handle h, int32_t part,
+                     const double *dev_inter_scores, const uint8_t *dev_intra_choice,
+                     const double *dev_traffic_bits, const float *dev_se_tiles,
+                     float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
+                     void *stream);
+int ranenv_wait_part(ranenv_handle h, int32_t part, void *stream);
+int ranenv_get_partition(ranenv_handle h, int32_t part, int32_t *env_first, int32_t *env_count);
+int ranenv_get_part_stream(ranenv_handle h, int32_t part, void **stream);
+
 /* How steps and resets read SE tiles replayed from the bound pool.
  *   RANENV_SE_STREAM (default)  every TTI streams the env's whole U x R tile: per UE the sum over all RBs (its mean is
  *                               what the observation, PF / MT and MAPF consume: agents/ib_sched.py:110-116,146-157,

@@ -25,7 +25,8 @@ EXPORTS = (
     "ranenv_launch_info", "ranenv_se_from_power", "ranenv_bind_head_outputs", "ranenv_set_slice_usecase",
     "ranenv_set_traffic_generator", "ranenv_set_max_steps", "ranenv_set_episode_table", "ranenv_set_autoreset",
     "ranenv_autoreset", "ranenv_get_poisson_tables", "ranenv_set_partitions", "ranenv_rollout", "ranenv_enable_metrics", "ranenv_get_metrics",
-    "ranenv_step_range", "ranenv_set_se_mode", "ranenv_get_se_sidecars",
+    "ranenv_step_range", "ranenv_set_se_mode", "ranenv_get_se_sidecars", "ranenv_step_part", "ranenv_wait_part",
+    "ranenv_get_partition", "ranenv_get_part_stream",
 )
 
 
@@ -108,6 +109,10 @@ def load() -> C.CDLL:
     lib.ranenv_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.ranenv_step.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     lib.ranenv_step_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9
+    lib.ranenv_step_part.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 9
+    lib.ranenv_wait_part.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.ranenv_get_part_stream.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.ranenv_get_partition.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ranenv_set_se_mode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.ranenv_get_se_sidecars.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
     lib.ranenv_set_partitions.argtypes = [C.c_void_p, C.c_int32]

@@ -99,7 +99,7 @@ class BatchedRanEnv:
         self._autoreset = False
         self.term_obs_inter = self.term_obs_intra = self.term_head_obs = None
         self.se_mode = "stream"
-        self._ranges = None          # set_ranges(): [(lo, hi, stream, done_event)] for step_async / step_wait
+        self._ranges = None          # set_ranges(): [(lo, hi)] for step_async / step_wait
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -362,51 +362,62 @@ class BatchedRanEnv:
 
     # -- a learner in the loop: ranges of the batch stepped alternately on their own streams -------------------------
     def set_ranges(self, n_ranges: int = 2):
-        """Cut the batch into ``n_ranges`` contiguous ranges, each with its own HIP stream, for ``step_async`` /
-        ``step_wait``: while the policy consumes one range's observations, the other ranges' TTIs occupy the GPU (the
-        reference trains through env.step with 10 concurrent env runners, simu.py:555-566, agents/ray_agent.py:296-300)."""
-        if n_ranges < 1 or n_ranges > self.B:
-            raise RanEnvError("n_ranges must be in [1, batch]")
-        base, rem = divmod(self.B, n_ranges)
-        lo, self._ranges = 0, []
-        with torch.cuda.device(self.device):
-            for k in range(n_ranges):
-                hi = lo + base + (1 if k < rem else 0)
-                self._ranges.append((lo, hi, torch.cuda.Stream(self.device), torch.cuda.Event()))
-                lo = hi
-        return [(lo, hi) for lo, hi, _, _ in self._ranges]
+        """Cut the batch into ``n_ranges`` contiguous ranges (the batch partitions of ``set_partitions``), each with its
+        own HIP stream, for ``step_async`` / ``step_wait``: while the policy consumes one range's observations, the other
+        ranges' TTIs occupy the GPU (the reference trains through env.step with 10 concurrent env runners,
+        simu.py:555-566, agents/ray_agent.py:296-300).  Returns the ranges [(lo, hi), ...]."""
+        self.set_partitions(n_ranges)
+        lo, n = C.c_int32(), C.c_int32()
+        self._ranges = []
+        for k in range(n_ranges):
+            self._check(self._lib.ranenv_get_partition(self._h, k, C.byref(lo), C.byref(n)), "ranenv_get_partition")
+            self._ranges.append((lo.value, lo.value + n.value))
+        self._range_out = [({"obs_inter": self.obs_inter[lo:hi], "obs_intra": self.obs_intra[lo:hi]}, self.reward[lo:hi],
+                            self.done[lo:hi]) for lo, hi in self._ranges]
+        self._range_streams = {}
+        return list(self._ranges)
+
+    def range_stream(self, k: int) -> "torch.cuda.Stream":
+        """Range ``k``'s own HIP stream as a torch stream.  A learner that runs range k's policy inside
+        ``with torch.cuda.stream(env.range_stream(k)):`` and calls ``step_wait(k)`` / ``step_async(k, ...)`` there makes
+        range k one in-order chain TTI -> policy -> TTI on one hardware queue: no event crosses between queues (each such
+        hop costs ~15 us on this GPU), and the ranges' chains overlap on the GPU like concurrent env runners."""
+        if self._ranges is None:
+            raise RanEnvError("range_stream needs set_ranges() first")
+        if k not in self._range_streams:
+            p = C.c_void_p()
+            self._check(self._lib.ranenv_get_part_stream(self._h, int(k), C.byref(p)), "ranenv_get_part_stream")
+            self._range_streams[k] = torch.cuda.ExternalStream(p.value, device=self.device)
+        return self._range_streams[k]
 
     def step_async(self, k: int, inter_scores=None, intra_choice=None, traffic_bits=None, se_tiles=None):
         """Enqueue one TTI of range ``k`` on that range's stream, ordered behind what the caller's current stream holds
         now (the kernels that produced the scores).  The arguments are whole-batch tensors ([B, ...], already on the
-        device: nothing is converted here); only range k's rows are read and written.  Returns at once; pair with
-        ``step_wait(k)``."""
+        device: nothing is converted here); only range k's rows are read and written, and the caller must leave those
+        rows alone until ``step_wait(k)``.  Returns at once (one library call: ranenv_step_part)."""
         if self._ranges is None:
             raise RanEnvError("step_async needs set_ranges() first")
         if self._recorder is not None or self._autoreset:
             raise RanEnvError("step_async does not run the recorder / auto-reset hooks: use step()")
-        lo, hi, stream, done = self._ranges[k]
         for name, x, dt in (("inter_scores", inter_scores, torch.float64), ("intra_choice", intra_choice, torch.uint8),
                             ("traffic_bits", traffic_bits, torch.float64), ("se_tiles", se_tiles, torch.float32)):
-            if x is not None and not (isinstance(x, torch.Tensor) and x.device == self.device and x.dtype == dt
-                                      and x.is_contiguous() and x.shape[0] == self.B):
+            if x is not None and not (x.dtype == dt and x.device == self.device and x.shape[0] == self.B and x.is_contiguous()):
                 raise RanEnvError(f"step_async: {name} must be a contiguous {dt} tensor [B, ...] on {self.device}")
-        stream.wait_stream(torch.cuda.current_stream(self.device))
-        st = self._lib.ranenv_step_range(self._h, lo, hi - lo, _ptr(inter_scores), _ptr(intra_choice), _ptr(traffic_bits),
-                                         _ptr(se_tiles), *self._p_out, C.c_void_p(stream.cuda_stream))
+        st = self._lib.ranenv_step_part(self._h, k, _ptr(inter_scores), _ptr(intra_choice), _ptr(traffic_bits), _ptr(se_tiles),
+                                        *self._p_out, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if st != 0:
-            self._check(st, "ranenv_step_range")
-        done.record(stream)
-        for x in (inter_scores, intra_choice, traffic_bits, se_tiles):     # the caching allocator must not recycle them early
-            if x is not None:
-                x.record_stream(stream)
+            self._check(st, "ranenv_step_part")
+        # the inputs are read on the range's stream: they stay referenced here until the range's next launch (their
+        # memory must not go back to the caching allocator meanwhile)
+        self._keep[("async_inputs", k)] = (inter_scores, intra_choice, traffic_bits, se_tiles)
 
     def step_wait(self, k: int):
         """Order the caller's current stream behind range ``k``'s last ``step_async`` (no host sync) and return views of
         that range's rows: ({"obs_inter", "obs_intra"}, reward, done)."""
-        lo, hi, _, done = self._ranges[k]
-        torch.cuda.current_stream(self.device).wait_event(done)
-        return ({"obs_inter": self.obs_inter[lo:hi], "obs_intra": self.obs_intra[lo:hi]}, self.reward[lo:hi], self.done[lo:hi])
+        st = self._lib.ranenv_wait_part(self._h, k, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if st != 0:
+            self._check(st, "ranenv_wait_part")
+        return self._range_out[k]
 
     def step_dense(self, sched_decision, traffic_bits=None, se_tiles=None):
         """One TTI with a caller-made dense sched_decision [B,U,R] (any agent's action_format)."""

@@ -1645,7 +1645,7 @@ struct ranenv {
     // their own stream, so that one partition's ramp and tail run under the other partitions' steady state
     int n_parts = 1;
     std::vector<hipStream_t> part_stream;
-    std::vector<hipEvent_t> part_done;
+    std::vector<hipEvent_t> part_done, part_in;
     std::vector<int> part_lo;
     hipEvent_t ev_in = nullptr;
     std::string err;
@@ -1944,6 +1944,7 @@ int ranenv_destroy(ranenv_handle h)
     (void)hipDeviceSynchronize();
     for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->part_done) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->part_in) if (e) (void)hipEventDestroy(e);
     for (auto &st : h->part_stream) if (st) (void)hipStreamDestroy(st);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     for (void *p : h->allocs) (void)hipFree(p);
@@ -2163,6 +2164,54 @@ int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count, con
     return RANENV_OK;
 }
 
+int ranenv_step_part(ranenv_handle h, int32_t part, const double *scores, const uint8_t *intra, const double *traffic_bits,
+                     const float *se_tiles, float *obs_inter, float *obs_intra, double *reward, uint8_t *done, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (part < 0 || part >= h->n_parts || h->part_lo.empty()) return fail(h, RANENV_E_INVALID, "partition %d outside [0,%d) (ranenv_set_partitions)", part, h->n_parts);
+    hipStream_t stream = (hipStream_t)stream_, ps = h->part_stream[(size_t)part];
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    // the partition's stream picks up behind what the caller's stream holds now (the producer of the scores) -- unless the
+    // caller works on the partition's stream itself (ranenv_get_part_stream): then stream order is all that is needed, and
+    // no signal crosses between hardware queues (a cross-queue dependency costs ~15 us each way on this GPU)
+    if (stream != ps) {
+        HIP_TRY(h, hipEventRecord(h->part_in[(size_t)part], stream));
+        HIP_TRY(h, hipStreamWaitEvent(ps, h->part_in[(size_t)part], 0));
+    }
+    const int rc = ranenv_step_range(h, h->part_lo[(size_t)part], h->part_lo[(size_t)part + 1] - h->part_lo[(size_t)part], scores, intra,
+                                     traffic_bits, se_tiles, obs_inter, obs_intra, reward, done, ps);
+    if (rc != RANENV_OK) return rc;
+    // ... and leaves an event for ranenv_wait_part
+    HIP_TRY(h, hipEventRecord(h->part_done[(size_t)part], ps));
+    return RANENV_OK;
+}
+
+int ranenv_wait_part(ranenv_handle h, int32_t part, void *stream_)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (part < 0 || part >= h->n_parts || h->part_lo.empty()) return fail(h, RANENV_E_INVALID, "partition %d outside [0,%d) (ranenv_set_partitions)", part, h->n_parts);
+    if ((hipStream_t)stream_ != h->part_stream[(size_t)part])
+        HIP_TRY(h, hipStreamWaitEvent((hipStream_t)stream_, h->part_done[(size_t)part], 0));
+    return RANENV_OK;
+}
+
+int ranenv_get_part_stream(ranenv_handle h, int32_t part, void **stream)
+{
+    if (!h || !stream) return fail(h, RANENV_E_INVALID, "null argument");
+    if (part < 0 || part >= h->n_parts || h->part_lo.empty()) return fail(h, RANENV_E_INVALID, "partition %d outside [0,%d) (ranenv_set_partitions)", part, h->n_parts);
+    *stream = (void *)h->part_stream[(size_t)part];
+    return RANENV_OK;
+}
+
+int ranenv_get_partition(ranenv_handle h, int32_t part, int32_t *env_first, int32_t *env_count)
+{
+    if (!h || !env_first || !env_count) return fail(h, RANENV_E_INVALID, "null argument");
+    if (h->part_lo.empty()) { if (part != 0) return fail(h, RANENV_E_INVALID, "partition %d outside [0,1)", part); *env_first = 0; *env_count = h->cfg.batch; return RANENV_OK; }
+    if (part < 0 || part >= h->n_parts) return fail(h, RANENV_E_INVALID, "partition %d outside [0,%d)", part, h->n_parts);
+    *env_first = h->part_lo[(size_t)part]; *env_count = h->part_lo[(size_t)part + 1] - h->part_lo[(size_t)part];
+    return RANENV_OK;
+}
+
 int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream_)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
@@ -2251,6 +2300,9 @@ int ranenv_set_partitions(ranenv_handle h, int32_t n_parts)
         h->part_stream.push_back(st);
         HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         h->part_done.push_back(ev);
+        ev = nullptr;
+        HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        h->part_in.push_back(ev);
     }
     if (!h->ev_in) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     h->part_lo.assign((size_t)n_parts + 1, 0);

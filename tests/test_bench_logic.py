@@ -41,10 +41,17 @@ assert env.n == K
 gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
 assert gathered.shape == (world, 8)
 args = types.SimpleNamespace(steps=K, warmup=2, config=2, traces=4, trace_len=5)
-line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, elapsed, 0.5, 2 * K, 2, None, summarize(gathered))
-if rank == 0:
-    print("LINE " + json.dumps(line), flush=True)
-print(f"RANK {rank} elapsed {elapsed!r} lo {lo} hi {hi}", flush=True)
+# blocks of exactly K steps, repeated until the sample is long enough: every rank must derive the same repeat count
+n0 = env.n
+times = bench.timed_blocks(lambda: [env.step() for _ in range(K)], lambda: None, dist.barrier, max_over_ranks, sample_s=0.05)
+assert len(times) >= 2 and (env.n - n0) == K * (len(times) + 1)
+line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, [elapsed], 0.5, 2 * K, 2, None, summarize(gathered),
+                        extras={"pipelined_step": bench.block_stats(times, B * world * K, K)})
+# one file per rank: two ranks printing at once can interleave on the launcher's pipe
+with open(os.path.join(os.environ["OUT_DIR"], f"rank{rank}.txt"), "w") as f:
+    if rank == 0:
+        f.write("LINE " + json.dumps(line) + "\n")
+    f.write(f"RANK {rank} elapsed {elapsed!r} lo {lo} hi {hi} repeats {len(times)}\n")
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -52,21 +59,25 @@ dist.barrier(); dist.destroy_process_group()
 def test_bench_rank_logic_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", OUT_DIR=str(tmp_path))
     port = 29500 + (os.getpid() % 2000)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("LINE ")]
-    ranks = sorted(l for l in out.stdout.splitlines() if l.startswith("RANK "))
+    text = "".join((tmp_path / f"rank{r}.txt").read_text() for r in range(2))
+    lines = [l for l in text.splitlines() if l.startswith("LINE ")]
+    ranks = sorted(l for l in text.splitlines() if l.startswith("RANK "))
     assert len(lines) == 1 and len(ranks) == 2
+    assert ranks[0].split()[-1] == ranks[1].split()[-1]         # the same repeat count on both ranks
     line = json.loads(lines[0][5:])
     K, B, world = 7, 8, 2
     e0, e1 = (float(r.split()[3]) for r in ranks)
     assert e0 == e1                                             # both ranks report the MAX over ranks ...
     assert e0 >= K * 0.004                                      # ... which is the slow rank's time
-    assert ranks[0].endswith("lo 0 hi 8") and ranks[1].endswith("lo 8 hi 16")
+    assert "lo 0 hi 8" in ranks[0] and "lo 8 hi 16" in ranks[1]
+    assert line["repeats"] == 1 and line["pipelined_step"]["repeats"] >= 2
+    assert line["pipelined_step"]["value_min"] <= line["pipelined_step"]["value"] <= line["pipelined_step"]["value_max"]
     assert line["n_gpus"] == world and line["steps"] == K and line["scaling"] == "weak"
     assert line["value"] == pytest.approx(B * world * K / e0, rel=1e-9)          # whole-job aggregate
     assert line["ms_per_step"] == pytest.approx(e0 / K * 1e3, rel=1e-9)

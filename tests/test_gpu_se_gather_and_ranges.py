@@ -124,12 +124,14 @@ def test_gather_mode_keeps_streaming_for_explicit_tiles_and_dense_steps():
     a.env.close(); b.env.close()
 
 
-@pytest.mark.parametrize("se_mode", ["stream", "gather"])
-def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_mode):
+@pytest.mark.parametrize("se_mode,policy_on", [("stream", "caller"), ("gather", "caller"), ("stream", "range"), ("gather", "range")])
+def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_mode, policy_on):
     """A learner in the loop: the batch as two halves on two streams (set_ranges / step_async / step_wait).  The scores
-    of a half are produced on the caller's stream from that half's last observation (a stand-in policy: a function of
-    the observation, so any ordering slip between the streams changes the numbers), 30 TTIs, against the oracle."""
+    of a half are produced from that half's last observation (a stand-in policy: a function of the observation, so any
+    ordering slip between the streams changes the numbers) -- on the caller's one stream (events join the streams) or on
+    the half's own stream (range_stream: stream order alone) --, 30 TTIs, against the oracle."""
     _need_gpu()
+    import contextlib
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     from oracle import pyoracle
     S, U, R, G, Us, B, steps = 10, 100, 135, 1, 10, 48, 30
@@ -153,6 +155,7 @@ def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_m
         env.set_se_mode("gather")
     ranges = env.set_ranges(2)
     assert ranges == [(0, 24), (24, 48)]
+    on = (lambda k: torch.cuda.stream(env.range_stream(k))) if policy_on == "range" else (lambda k: contextlib.nullcontext())
     cfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps)
     oenvs = []
     for b in range(B):
@@ -172,10 +175,12 @@ def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_m
     ic = np.ones(S, dtype=np.int32)
     # prime the pipeline: both halves get their first TTI from the reset observation
     in_flight = [None, None]                  # the scores a half's TTI in flight was launched with (host copy: exact)
+    torch.cuda.synchronize()                  # the reset ran on the caller's stream
     for k, (lo, hi) in enumerate(ranges):
-        scores[lo:hi] = policy_dev(env.obs_inter[lo:hi])
-        in_flight[k] = scores[lo:hi].cpu().numpy()
-        env.step_async(k, scores, None)       # intra-slice scheduler fixed by set_policy
+        with on(k):
+            scores[lo:hi] = policy_dev(env.obs_inter[lo:hi])
+            in_flight[k] = scores[lo:hi].cpu().numpy()
+            env.step_async(k, scores, None)   # intra-slice scheduler fixed by set_policy
     host_obs = [o.obs() for o in oenvs]
     for k, (lo, hi) in enumerate(ranges):
         for j, b in enumerate(range(lo, hi)):
@@ -184,7 +189,15 @@ def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_m
     for it in range(2 * (steps - 1)):
         k = it % 2
         lo, hi = ranges[k]
-        obs, rew, done = env.step_wait(k)
+        with on(k):
+            obs, rew, done = env.step_wait(k)
+            # this half's next scores from its new observation; what the host checks below is copied out before the
+            # next TTI of the half is enqueued
+            scores[lo:hi] = policy_dev(obs["obs_inter"])
+            got_sc = scores[lo:hi].cpu().numpy()
+            g = {n: x[lo:hi].cpu().numpy() for n, x in env.views().items() if x.shape[0] == B}
+            goi, goa, grw = obs["obs_inter"].cpu().numpy(), obs["obs_intra"].cpu().numpy(), rew.cpu().numpy()
+            env.step_async(k, scores, None)
         # oracle: the TTI that was in flight for this half, with the very scores the device used
         sc_host = in_flight[k]
         for j, b in enumerate(range(lo, hi)):
@@ -193,12 +206,7 @@ def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_m
             o.step(sc_host[j], ic, se_pool[tile], trf[b * trace_len + t_of[k] % trace_len])
             host_obs[b] = o.obs()
         t_of[k] += 1
-        # next TTI of this half: its scores from its new observation, on the caller's stream
-        scores[lo:hi] = policy_dev(obs["obs_inter"])
-        got_sc = in_flight[k] = scores[lo:hi].cpu().numpy()
-        g = {n: x[lo:hi].cpu().numpy() for n, x in env.views().items() if x.shape[0] == B}
-        goi, goa, grw = obs["obs_inter"].cpu().numpy(), obs["obs_intra"].cpu().numpy(), rew.cpu().numpy()
-        env.step_async(k, scores, None)
+        in_flight[k] = got_sc
         for j, b in enumerate(range(lo, hi)):
             raw, oo = oenvs[b].raw(), host_obs[b]
             for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
@@ -208,7 +216,8 @@ def test_two_halves_stepped_alternately_with_scores_from_the_callers_stream(se_m
             np.testing.assert_allclose(grw[j], oo["reward"], rtol=0, atol=REW_TOL)
             np.testing.assert_allclose(got_sc[j], policy_host(oo), rtol=0, atol=1e-5)
     for k in range(2):
-        env.step_wait(k)
+        with on(k):
+            env.step_wait(k)
     torch.cuda.synchronize()
     env.close()
 
@@ -223,9 +232,17 @@ def test_step_range_argument_checks():
     env.set_ranges(2)
     with pytest.raises(RanEnvError, match="contiguous"):
         env.step_async(0, inter_scores=torch.zeros((4, env.S), dtype=torch.float64, device=env.device))
-    import ctypes as C
     st = env._lib.ranenv_step_range(env._h, 6, 4, None, None, None, None, None, None, None, None, None)
     assert st == -1 and b"outside the batch" in env._lib.ranenv_last_error(env._h)
+    st = env._lib.ranenv_step_part(env._h, 2, None, None, None, None, None, None, None, None, None)
+    assert st == -1 and b"partition 2 outside" in env._lib.ranenv_last_error(env._h)
+    assert env._lib.ranenv_wait_part(env._h, -1, None) == -1
+    # ranenv_step_range itself (any range, the caller's own stream): the second half alone moves on, the first stays
+    before = env.views()["step_number"].clone()
+    st = env._lib.ranenv_step_range(env._h, 4, 4, None, None, None, None, *env._p_out, None)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert (env.views()["step_number"] - before).cpu().tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
     env.close()
 
 
