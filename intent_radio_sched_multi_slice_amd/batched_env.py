@@ -333,7 +333,7 @@ class BatchedRanEnv:
                         "ranenv_reset")
         self._keep["last_inputs"] = (m, se)
         if self._recorder is not None:
-            self._recorder.on_reset()
+            self._recorder.on_reset(m)
         return self._obs()
 
     def step(self, inter_scores=None, intra_choice=None, traffic_bits=None, se_tiles=None):

@@ -49,9 +49,13 @@ class HistoryRecorder:
     """Traces of selected envs of a BatchedRanEnv, accumulated on the device (a few small gathers on the env's
     stream after every step), written as reference-format history files when the env reports ``done``.
 
-    ``episode_numbers[i]`` is the episode number env ``envs[i]`` is playing (it names the file and is advanced
-    by one after every write).  Association / intent columns come from the scenario pool row the env replays; the
-    agent action recorded is the inter-slice score vector the step used and the intra-slice scheduler choices.
+    Every recorded env has its own step counter: envs may be reset under a mask, run episodes of different lengths
+    (``set_max_steps``) or move on to their next episode on the device (``enable_autoreset``: the recorder then takes
+    the episode number, the scenario and the channel trace of a new episode from the descriptors the device installed).
+    ``episode_numbers[i]`` is the episode number env ``envs[i]`` is playing when recording starts; it names the file and,
+    without device auto-reset, is advanced by one after every write.  Association / intent columns come from the
+    scenario pool row the env replays; the agent action recorded is the inter-slice score vector the step used and the
+    intra-slice scheduler choices.
     """
 
     def __init__(self, env, envs: Sequence[int], root_path: str = ".", simu_name: str = "mult_slice",
@@ -65,7 +69,9 @@ class HistoryRecorder:
             raise ValueError("recorded env index outside the batch")
         self.root_path, self.simu_name, self.agent_name, self.marl = root_path, simu_name, agent_name, marl
         self.episode_numbers = list(episode_numbers) if episode_numbers is not None else [0] * len(self.envs)
-        n, T, U, S = len(self.envs), env.max_steps, env.U, env.S
+        me = getattr(env, "max_steps_env", None)
+        n, U, S = len(self.envs), env.U, env.S
+        T = self.T = int(env.max_steps if me is None else np.asarray(me)[self.envs].max())
         z = lambda *sh, dt=torch.int32: torch.zeros(sh, dtype=dt, device=env.device)
         self.buf = {
             "pkt_incoming": z(T, n, U), "pkt_throughputs": z(T, n, U), "pkt_effective_thr": z(T, n, U),
@@ -76,61 +82,95 @@ class HistoryRecorder:
             "intra": z(T, n, S, dt=torch.uint8),
             "obs_inter": z(T, n, S * 10, dt=torch.float32), "obs_intra": z(T, n, S, env.W, dt=torch.float32),
         }
-        self.t = 0
-        self._scen_at_start = np.array(env.episode_descriptors()["scenario"])[self.envs]
+        self.t = np.zeros(n, dtype=np.int64)                 # steps recorded of every slot's current episode
+        self._cols = torch.arange(n, device=env.device)
+        self._stale = np.zeros(n, dtype=bool)                # the slot's episode changed on the device: re-read its descriptor
+        self._desc = None
+        self._refresh(np.arange(n))
         self.written: List[str] = []
 
-    def on_reset(self):
-        self.t = 0
-        self._scen_at_start = np.array(self.env.episode_descriptors()["scenario"])[self.envs]
+    def _refresh(self, slots):
+        """(Re-)read the episode descriptors -- scenario, channel trace -- of the given slots as they are on the device."""
+        eps = self.env.episode_descriptors()
+        if self._desc is None:
+            self._desc = np.array(eps[self.envs])
+        else:
+            self._desc[slots] = eps[np.asarray(self.envs)[slots]]
+        if self.env._autoreset:
+            num = self.env.views()["episode_number"].index_select(0, self.idx).cpu().numpy()
+            for k in slots:
+                self.episode_numbers[k] = int(num[k])
+        self._stale[slots] = False
+
+    def on_reset(self, env_mask=None):
+        """Called by BatchedRanEnv.reset: the masked envs (all without a mask) start an episode; what was recorded of
+        their unfinished one is dropped."""
+        if env_mask is None:
+            slots = np.arange(len(self.envs))
+        else:
+            m = env_mask.index_select(0, self.idx).cpu().numpy() if hasattr(env_mask, "index_select") else np.asarray(env_mask)[self.envs]
+            slots = np.nonzero(m)[0]
+        self.t[slots] = 0
+        if len(slots):
+            self._refresh(slots)
 
     def on_step(self, se_tiles, intra_choice, done):
-        """Called by BatchedRanEnv.step after the launch; ``se_tiles`` = explicit tiles of this step or None (pool)."""
-        torch, env, i, t = self._torch, self.env, self.idx, self.t
-        if t >= env.max_steps:
-            raise RuntimeError("recorder: more steps than max_steps without a reset")
+        """Called by BatchedRanEnv.step after the launch (and before an auto-reset is enqueued); ``se_tiles`` = explicit
+        tiles of this step or None (pool)."""
+        torch, env, i = self._torch, self.env, self.idx
+        if self._stale.any():
+            self._refresh(np.nonzero(self._stale)[0])
+        if (self.t >= self.T).any():
+            raise RuntimeError("recorder: an env ran past the longest episode length known when recording started "
+                               "(set_max_steps after record()?)")
+        tt, cols = torch.as_tensor(self.t, device=env.device), self._cols
         v = env.views()
         for k in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts", "queue_pkts", "queue_age_sum",
                   "rb_start", "rb_count"):
-            self.buf[k][t] = v[k].index_select(0, i)
-        self.buf["scores"][t] = v["policy_scores"].index_select(0, i)
-        self.buf["reward"][t] = env.reward.index_select(0, i)
-        self.buf["obs_inter"][t] = env.obs_inter.index_select(0, i)
-        self.buf["obs_intra"][t] = env.obs_intra.index_select(0, i)
+            self.buf[k][tt, cols] = v[k].index_select(0, i)
+        self.buf["scores"][tt, cols] = v["policy_scores"].index_select(0, i)
+        self.buf["reward"][tt, cols] = env.reward.index_select(0, i)
+        self.buf["obs_inter"][tt, cols] = env.obs_inter.index_select(0, i)
+        self.buf["obs_intra"][tt, cols] = env.obs_intra.index_select(0, i)
         if intra_choice is not None:
-            self.buf["intra"][t] = intra_choice.index_select(0, i)
+            self.buf["intra"][tt, cols] = intra_choice.index_select(0, i)
         else:
-            self.buf["intra"][t] = int(env.fixed_intra if env.fixed_intra != 255 else 0)
+            self.buf["intra"][tt, cols] = int(env.fixed_intra if env.fixed_intra != 255 else 0)
         if se_tiles is not None:
-            self.buf["se"][t] = se_tiles.index_select(0, i)
+            self.buf["se"][tt, cols] = se_tiles.index_select(0, i)
         else:
-            eps = env.episode_descriptors()
-            tile = eps["se_base"][self.envs] + (eps["se_offset"][self.envs] + t) % eps["se_len"][self.envs]
-            self.buf["se"][t] = env._keep["se_pool"].index_select(0, torch.as_tensor(tile, device=env.device))
-        self.t = t + 1
+            d = self._desc
+            tile = d["se_base"] + (d["se_offset"] + self.t) % d["se_len"]
+            self.buf["se"][tt, cols] = env._keep["se_pool"].index_select(0, torch.as_tensor(tile, device=env.device))
+        self.t += 1
         d = done.index_select(0, i).cpu().numpy().astype(bool)         # recording is a diagnostic mode: one small sync
         if d.any():
-            self.flush([k for k in range(len(self.envs)) if d[k]])
+            which = [k for k in range(len(self.envs)) if d[k]]
+            self.flush(which)
+            self.t[which] = 0
+            if env._autoreset:
+                self._stale[which] = True                              # the device installs the next episode after this call
 
     def flush(self, which: Optional[Sequence[int]] = None) -> List[str]:
-        """Write the steps recorded so far for recorder slots ``which`` (all by default)."""
-        env, T = self.env, self.t
+        """Write the steps recorded so far of the current episode of recorder slots ``which`` (all by default)."""
+        env = self.env
         which = list(range(len(self.envs))) if which is None else list(which)
-        host = {k: b[:T].cpu().numpy() for k, b in self.buf.items()}
+        Tmax = int(self.t[which].max()) if which else 0
+        host = {k: b[:Tmax].cpu().numpy() for k, b in self.buf.items()}
         S, U, R, Us = env.S, env.U, env.R, env.Us
         paths = []
         for k in which:
-            e = self.envs[k]
-            scen = int(self._scen_at_start[k])
+            T = int(self.t[k])
+            scen = int(self._desc["scenario"][k])
             bua, bsa, sua, req = env.tables.to_reference(scen)
             max_pkts = env.tables.ue_max_pkts[scen].astype(np.float64)
-            q = host["queue_pkts"][:, k].astype(np.float64)
-            age = host["queue_age_sum"][:, k].astype(np.float64)
+            q = host["queue_pkts"][:T, k].astype(np.float64)
+            age = host["queue_age_sum"][:T, k].astype(np.float64)
             lat = np.where(q > 0, age / np.maximum(q, 1.0), 0.0)
-            st, cn = host["rb_start"][:, k], host["rb_count"][:, k]
+            st, cn = host["rb_start"][:T, k], host["rb_count"][:T, k]
             r = np.arange(R)[None, None, :]
             sched = ((r >= st[:, :, None]) & (r < (st + cn)[:, :, None])).astype(np.float64)[:, None]   # (T, 1, U, R)
-            se = np.swapaxes(host["se"][:, k], 1, 2).astype(np.float64)[:, None]                         # (T, 1, U, R)
+            se = np.swapaxes(host["se"][:T, k], 1, 2).astype(np.float64)[:, None]                        # (T, 1, U, R)
             mask_inter = np.asarray(env.tables.slice_active[scen], dtype=np.int8)
             nues = env.tables.slice_nues[scen]
             obs, rew, act = [], [], []
@@ -151,17 +191,18 @@ class HistoryRecorder:
                     act.append(host["scores"][t, k].copy())
             rep = lambda a: np.repeat(np.asarray(a)[None], T, axis=0)
             hist = {
-                "pkt_incoming": host["pkt_incoming"][:, k].astype(np.float64),
-                "pkt_throughputs": host["pkt_throughputs"][:, k].astype(np.float64),
-                "pkt_effective_thr": host["pkt_effective_thr"][:, k].astype(np.float64),
+                "pkt_incoming": host["pkt_incoming"][:T, k].astype(np.float64),
+                "pkt_throughputs": host["pkt_throughputs"][:T, k].astype(np.float64),
+                "pkt_effective_thr": host["pkt_effective_thr"][:T, k].astype(np.float64),
                 "buffer_occupancies": q / max_pkts[None, :], "buffer_latencies": lat,
-                "dropped_pkts": host["dropped_pkts"][:, k].astype(np.float64),
+                "dropped_pkts": host["dropped_pkts"][:T, k].astype(np.float64),
                 "mobility": np.ones((T, U, 2)), "spectral_efficiencies": se,
                 "basestation_ue_assoc": rep(bua), "basestation_slice_assoc": rep(bsa), "slice_ue_assoc": rep(sua),
                 "sched_decision": sched, "reward": rew, "slice_req": [req] * T, "obs": obs, "agent_action": act,
             }
             paths.append(write_episode_npz(hist_path(self.root_path, self.simu_name, self.agent_name,
                                                      self.episode_numbers[k]), hist))
-            self.episode_numbers[k] += 1
+            if not env._autoreset:
+                self.episode_numbers[k] += 1
         self.written += paths
         return paths
