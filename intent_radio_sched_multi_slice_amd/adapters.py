@@ -37,10 +37,42 @@ class _Box:
         self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
 
 
+class _Discrete:
+    """Stand-in for gymnasium.spaces.Discrete when gymnasium is absent."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+
+class _Dict:
+    """Stand-in for gymnasium.spaces.Dict when gymnasium is absent."""
+
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+
+
 def _box(low, high, shape, dtype):
     if _spaces is not None:
         return _spaces.Box(low=low, high=high, shape=tuple(shape), dtype=dtype)
     return _Box(low, high, shape, dtype)
+
+
+def _discrete(n):
+    return _spaces.Discrete(n) if _spaces is not None else _Discrete(n)
+
+
+def _dict(spaces):
+    return _spaces.Dict(spaces) if _spaces is not None else _Dict(spaces)
+
+
+def describe_space(sp) -> dict:
+    """A space (gymnasium's or the stand-ins above) as plain data: nested dicts of {"shape", "low", "high", "dtype"} /
+    {"discrete": n}."""
+    if hasattr(sp, "spaces"):
+        return {k: describe_space(v) for k, v in sp.spaces.items()}
+    if hasattr(sp, "n"):
+        return {"discrete": int(sp.n)}
+    return {"shape": list(sp.shape), "low": float(np.min(sp.low)), "high": float(np.max(sp.high)), "dtype": np.dtype(sp.dtype).name}
 
 
 class HeadVecEnv(_VecEnvBase):
@@ -188,6 +220,10 @@ class MarlBatchEnv:
     over S of masked_action_distribution.py), "player_{s+1}": [B] integers in {0, 1, 2} (Discrete(3): RR / PF / MT)}``.
     Reward: ``{"player_i": float64 [B]}``; terminated: ``{"player_i": bool [B], "__all__": bool [B]}`` (simu.py:559-564).
     All tensors are views of the env's buffers (zero copy); nothing here synchronises with the host.
+    ``observation_space`` / ``action_space``: one env's spaces as IBSched.get_obs_space / get_action_space declare them
+    (agents/ib_sched.py:394-470; gymnasium's classes when installed), with two differences: the per-slice observation has
+    ``2 * max_ues_slice + 9`` entries (the reference hard-codes max_number_ues / max_number_slices UEs per slice) and
+    observations are declared float32, which is what the device hands out.
     """
 
     def __init__(self, env: BatchedRanEnv):
@@ -195,6 +231,13 @@ class MarlBatchEnv:
         env.set_policy(POLICY_EXTERNAL, 255)           # scores and schedulers come with every action
         self.players = [f"player_{i}" for i in range(env.S + 1)]
         self._intra = torch.zeros((env.B, env.S), dtype=torch.uint8, device=env.device)
+        S, Us = env.S, env.Us
+        self.action_space = _dict({p: (_box(-1, 1, (S,), np.float64) if i == 0 else _discrete(3))       # :394-411
+                                   for i, p in enumerate(self.players)})
+        self.observation_space = _dict({                                                                  # :413-470
+            p: _dict({"observations": _box(-1, np.inf, (S * 10,) if i == 0 else (2 * Us + 9,), np.float32),
+                      "action_mask": _box(0.0, 1.0, (S,) if i == 0 else (Us,), np.int8)})
+            for i, p in enumerate(self.players)})
 
     def _obs(self):
         env, v = self.env, self.env.views()

@@ -1,0 +1,131 @@
+"""tests/golden/agents_on_facade.npz replayed through the real facade on the GPU.
+
+The fixture was produced in the build container by the reference's REAL classes -- agents/ib_sched.py IBSched,
+agents/marr.py MARR, agents/mapf.py MAPF, associations/mult_slice.py, traffics/mult_slice.py, channels/mimic_quadriga.py,
+mobilities/simple.py -- attached to comm_env.MARLCommEnv by env_creator's sequence (simu.py:341-424) with a CPU stand-in
+under the facade (tests/golden/gen_golden_agents.py).  Here the same facade runs on the HIP env step with this build's
+plugins (same seed: the four plugins share the env's one rng, so traffic and channel only agree if every plugin draws what
+and when the reference's does) and the fixture's actions; an agent that speaks the reference's protocol with the oracle's
+agent-side arithmetic formats observations.  Integers (RB ranges, traffic, packets in / out / dropped) must match exactly,
+dict observations at 1e-5, rewards at 1e-9."""
+import json
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.common import load_golden
+from tests.test_gpu_protocol_agent import OracleIBSched
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL, REW_TOL = 1e-5, 1e-9
+
+
+class _Agent(OracleIBSched):
+    """IBSched's protocol; ``sort`` = enable_sort_slices (MARR / MAPF wrap an IBSched built with it off, agents/marr.py:30-37)."""
+
+    def __init__(self, *a, sort=True, **k):
+        super().__init__(*a, **k)
+        self._sort = sort
+
+    def _sync_scenario(self, raw):
+        from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables
+        ues = self.env.comm_env.ues
+        key = (raw["slice_ue_assoc"].tobytes(), ues.pkt_sizes.tobytes(), ues.max_buffer_pkts.tobytes())
+        if key != self._scenario_key:
+            t = ScenarioTables.empty(1, self.S, self.U, self.Us)
+            t.set_from_reference(0, raw["basestation_slice_assoc"], raw["slice_ue_assoc"], raw["slice_req"], self._sort,
+                                 (ues.pkt_sizes, ues.max_buffer_pkts, np.array([b.max_packets_age for b in ues.buffers])))
+            self.tables = t
+            self.orc.set_scenario(t, 0)
+            self._scenario_key = key
+
+
+@pytest.mark.parametrize("name", ["ib_sched", "marr", "mapf"])
+def test_fixture_of_the_real_reference_agents_replays_on_the_gpu_facade(name, tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    replay_fixture(name, tmp_path)
+
+
+def replay_fixture(name, tmp_path):
+    """(also run by tests/test_reference_agents_cpu.py with the CPU stand-in under the facade)"""
+    from intent_radio_sched_multi_slice_amd import plugins
+    from intent_radio_sched_multi_slice_amd.comm_env import DEFAULT_CONFIGS, MARLCommEnv
+    fx = load_golden("agents_on_facade")
+    S, U, R, G, Us, seed, steps = (int(x) for x in fx["cfg"])
+    cfg = dict(DEFAULT_CONFIGS["mult_slice"], max_number_steps=steps)
+    env = MARLCommEnv(plugins.MimicQuadriga, plugins.MultSliceTraffic, plugins.SimpleMobility, plugins.MultSliceAssociation,
+                      "mult_slice", name, seed, root_path=str(tmp_path), config=cfg, max_episode_number=2, max_ues_slice=Us)
+    ce = env.comm_env
+    marl = name == "ib_sched"
+    agent = _Agent(env, ce.max_number_ues, ce.max_number_slices, ce.max_number_basestations, ce.num_available_rbs,
+                   max_ues_slice=Us, rbs_per_rbg=G, sort=marl)
+    env.set_agent_functions(agent.obs_space_format, agent.action_format, agent.calculate_reward, None, None)
+    fixed = {"ib_sched": None, "marr": 0, "mapf": 1}[name]      # MARR: fixed_intra "rr" (marr.py:62-70), MAPF: "pf" (mapf.py:126-134)
+
+    def flat(o):
+        if marl:
+            return (np.concatenate([o["player_0"]["observations"]] + [o[f"player_{s + 1}"]["observations"] for s in range(S)]),
+                    np.concatenate([o["player_0"]["action_mask"]] + [o[f"player_{s + 1}"]["action_mask"] for s in range(S)]))
+        return np.asarray(o["player_0"]["observations"]), None
+
+    obs, _ = env.reset(seed=seed, options={"initial_episode": 0})
+    assert np.array_equal(ce.slice_ue_assoc, fx[f"{name}_slice_ue_assoc"])
+    assert {k: (v["name"] if v else None) for k, v in ce.slice_req.items()} == json.loads(str(fx[f"{name}_slice_names"]))
+    assert np.array_equal(np.stack([ce.ues.pkt_sizes, ce.ues.max_buffer_pkts, ce.ues.max_buffer_latencies]), fx[f"{name}_ues"])
+    o, m = flat(obs)
+    np.testing.assert_allclose(o, fx[f"{name}_reset_obs"], rtol=0, atol=OBS_TOL)
+    if marl:
+        assert np.array_equal(m, fx[f"{name}_reset_mask"])
+    for t in range(steps):
+        a = fx[f"{name}_action"][t]
+        action = {"player_0": a[:S].copy()}
+        action.update({f"player_{s + 1}": int(a[S + s]) if marl else fixed for s in range(S)})
+        obs, reward, term, trunc, info = env.step(action)
+        raw = env._last_raw
+        sched = np.asarray(raw["sched_decision"])[0]
+        cnt = sched.sum(axis=1).astype(np.int32)
+        assert np.array_equal(cnt, fx[f"{name}_rb_count"][t]), (name, t)
+        st = np.array([int(np.nonzero(sched[u])[0][0]) if cnt[u] else 0 for u in range(U)])
+        assert np.array_equal(st, fx[f"{name}_rb_start"][t]), (name, t)
+        assert np.array_equal(env._last_traffic, fx[f"{name}_traffic"][t]), (name, t)
+        np.testing.assert_array_equal(np.asarray(raw["spectral_efficiencies"])[0].sum(axis=1), fx[f"{name}_se_sum"][t])
+        for k in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts", "buffer_occupancies", "buffer_latencies"):
+            assert np.array_equal(raw[k], fx[f"{name}_{k}"][t]), (name, t, k)
+        o, m = flat(obs)
+        np.testing.assert_allclose(o, fx[f"{name}_obs"][t], rtol=0, atol=OBS_TOL, err_msg=str((name, t)))
+        if marl:
+            assert np.array_equal(m, fx[f"{name}_mask"][t])
+            rw = np.array([reward[f"player_{i}"] for i in range(S + 1)])
+        else:
+            rw = np.array([reward["player_0"]])
+        np.testing.assert_allclose(rw, fx[f"{name}_reward"][t], rtol=0, atol=REW_TOL, err_msg=str((name, t)))
+    assert term["__all__"]
+    env.close()
+
+
+def test_batched_marl_view_carries_the_reference_spaces():
+    """adapters.MarlBatchEnv.observation_space / action_space against IBSched.get_obs_space / get_action_space as the
+    reference's class returned them (agents/ib_sched.py:394-470)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.adapters import MarlBatchEnv, describe_space
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    fx = load_golden("agents_on_facade")
+    want = json.loads(str(fx["ib_sched_spaces"]))
+    wl = make_mult_slice_workload(4, torch.device("cuda", 0), n_scenarios=4, n_traces=2, trace_len=4, n_slices=5, n_ues=25,
+                                  n_rbs=135, rbs_per_rbg=5, max_ues_slice=5, max_steps=4)
+    menv = MarlBatchEnv(wl.env)
+    for p in want["obs"]:                 # the reference declares float64 observations; the device hands out float32
+        assert want["obs"][p]["observations"]["dtype"] == "float64"
+        want["obs"][p]["observations"]["dtype"] = "float32"
+    assert describe_space(menv.observation_space) == want["obs"]
+    assert describe_space(menv.action_space) == want["action"]
+    obs, _ = menv.reset()
+    for p, sp in menv.observation_space.spaces.items():
+        assert tuple(obs[p]["observations"].shape[1:]) == tuple(sp.spaces["observations"].shape)
+        assert tuple(obs[p]["action_mask"].shape[1:]) == tuple(sp.spaces["action_mask"].shape)
+    wl.env.close()
