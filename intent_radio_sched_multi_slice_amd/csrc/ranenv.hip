@@ -170,8 +170,13 @@ DEVFN bool d_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * 
 // in this file zero-pads its rows), so no per-element select is needed; all 16 reads issue back to back.
 // Of numpy's three shapes only those some lane of the wave needs are evaluated (wave-uniform tests):
 // an instruction costs the same with one active lane as with 64.
-DEVFN double np_sum16_lds(const double *row, int n)
+// NP (template) = how many leading entries of a row can be non-zero at all in this build of the kernel (the largest slice /
+// the number of slices, rounded up to 8, 10 or 16): entries from NP on are never read, their additions (+0.0) never issued.
+template <int NP>
+DEVFN double np_sum_lds(const double *row, int n)
 {
+    static_assert(NP >= 8 && NP <= 16, "row builds: 8, 10, 16");
+    constexpr int NY = NP - 8;             // entries of the second half that can be non-zero
     // The two halves of the row are read one after the other, so that 8 (not 16) doubles are alive at a time in the
     // common shapes; only numpy's n == 16 shape pairs element j with element 8 + j and re-reads the first half.
     double res = 0.0;
@@ -186,25 +191,27 @@ DEVFN double np_sum16_lds(const double *row, int n)
     const bool mid = n >= 8 && n < 16;
     if (__builtin_amdgcn_ballot_w64(mid) != 0)
         t8 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-    if (__builtin_amdgcn_ballot_w64(n >= 8) != 0) {
-        double y[8];
+    if (NY > 0 && __builtin_amdgcn_ballot_w64(n > 8) != 0) {            // (n == 8: the tree alone, nothing to add)
+        double y[NY > 0 ? NY : 1];
 #pragma unroll
-        for (int j = 0; j < 8; j++) y[j] = row[8 + j];
+        for (int j = 0; j < NY; j++) y[j] = row[8 + j];
         if (__builtin_amdgcn_ballot_w64(mid) != 0) {
 #pragma unroll
-            for (int j = 0; j < 7; j++) t8 += y[j];
-            res = mid ? t8 : res;
+            for (int j = 0; j < (NY < 7 ? NY : 7); j++) t8 += y[j];
         }
-        if (__builtin_amdgcn_ballot_w64(n >= 16) != 0) {
+        if constexpr (NP == 16) {
+            if (__builtin_amdgcn_ballot_w64(n >= 16) != 0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = row[j];
-            const double t16 = (((x[0] + y[0]) + (x[1] + y[1])) + ((x[2] + y[2]) + (x[3] + y[3]))) +
-                               (((x[4] + y[4]) + (x[5] + y[5])) + ((x[6] + y[6]) + (x[7] + y[7])));
-            res = n >= 16 ? t16 : res;
+                for (int j = 0; j < 8; j++) x[j] = row[j];
+                const double t16 = (((x[0] + y[0]) + (x[1] + y[1])) + ((x[2] + y[2]) + (x[3] + y[3]))) +
+                                   (((x[4] + y[4]) + (x[5] + y[5])) + ((x[6] + y[6]) + (x[7] + y[7])));
+                res = n >= 16 ? t16 : res;
+            }
         }
     }
-    return res;
+    return mid ? t8 : res;
 }
+DEVFN double np_sum16_lds(const double *row, int n) { return np_sum_lds<16>(row, n); }
 
 DEVFN bool d_apply_op(int op, double a, double b)
 {
@@ -306,6 +313,9 @@ DEVFN RowPlan make_row_plan(int n)
                                   the queue's last turn, 2: after the stream (default: ~20 registers fewer while the tile
                                   streams; with 8 loads in flight per lane the kernel fits 96 VGPRs = 5 waves per SIMD
                                   without spills; measured A/B in profiles/r02_ab_log.txt) */
+#endif
+#ifndef RANENV_GATHER_STATE_FIRST
+#define RANENV_GATHER_STATE_FIRST 0
 #endif
 #ifndef RANENV_COLD_ARGS
 #define RANENV_COLD_ARGS 1
@@ -597,6 +607,7 @@ DEVFN double *srow(SharedCore &sh, int s, int k) { return &sh.rows[s][k * GRP]; 
 // in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
 // in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
 // slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
+template <int NP>
 DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, int slc, int pos,
                        int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out)
 {
@@ -625,9 +636,9 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             double occ_mb = 0.0, thr_mb = 0.0;
             if (ok1 && active) {
                 const double pkt = (double)msg, bmax = (double)bsize;
-                occ_mb = ((np_sum16_lds(srow(sh, s1, 0), nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
+                occ_mb = ((np_sum_lds<NP>(srow(sh, s1, 0), nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
                 asm volatile("" : "+v"(occ_mb));     // one row at a time: both rows in registers at once set the kernel's VGPR peak
-                thr_mb = ((np_sum16_lds(srow(sh, s1, 1), nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+                thr_mb = ((np_sum_lds<NP>(srow(sh, s1, 1), nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
             }
             if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
             wave_sync();
@@ -635,14 +646,14 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             if (tid < GRP) {
                 double mx = xs[0][0];
 #pragma unroll
-                for (int j = 1; j < 16; j++) { const double v = xs[0][j]; mx = (j < S && v > mx) ? v : mx; }
+                for (int j = 1; j < NP; j++) { const double v = xs[0][j]; mx = (j < S && v > mx) ? v : mx; }
                 w = d_isclose(thr_mb, 0.0) ? 2.0 * mx : occ_mb / thr_mb;                            // :91-100
                 if (!active) w = 0.0;
                 xs[2][s1] = ok1 ? w : 0.0;
             }
             wave_sync();
             if (tid < GRP) {
-                const double ws = np_sum16_lds(xs[2], S);
+                const double ws = np_sum_lds<NP>(xs[2], S);
                 score = (ws > 0.0 ? w / ws : 2.0) - 1.0;                                            // :105-109
             }
             wave_sync();
@@ -664,7 +675,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
         double my_v = 0.0; bool nzf = false; int m_nz = 0, slot = 0;
         if (tid < GRP) {
             // np.sum(association) adds small integers: exact in any order, so an integer row sum does it
-            const double ssum = np_sum16_lds(xs[0], S), asum = (double)row16_sum(ok1 ? active : 0);
+            const double ssum = np_sum_lds<NP>(xs[0], S), asum = (double)row16_sum(ok1 ? active : 0);
             if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
             nzf = my_v != 0.0;
             // compaction of the non-zero values in slice order (common.py:484-485): they move to the front,
@@ -675,7 +686,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
         }
         wave_sync();
         if (tid < GRP) {
-            const double tot = np_sum16_lds(xs[2], m_nz);
+            const double tot = np_sum_lds<NP>(xs[2], m_nz);
             const int my_prop = nzf ? (int)((double)T * my_v / tot) : 0;                  // :488-490 (value >= 0)
             const int acc = row16_sum(my_prop);
             const int adj = T - acc;                                                     // :493-499
@@ -683,7 +694,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             if (nzf && adj > 0) {
                 int rank = 0;
 #pragma unroll
-                for (int j = 0; j < 16; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
+                for (int j = 0; j < NP; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
                 extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
             }
             const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
@@ -722,27 +733,27 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
             if (__builtin_amdgcn_ballot_w64(starved) != 0) {       // the slice maximum is only read by UEs that sent nothing
                 max_avail = r0[0];
 #pragma unroll
-                for (int k = 1; k < 16; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+                for (int k = 1; k < NP; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
             }
             num = starved ? 2.0 * max_avail : avail / snt;
         }
         if (have) r1[pos] = num;
         wg_sync();
-        const double wsum = np_sum16_lds(r1, n);
+        const double wsum = np_sum_lds<NP>(r1, n);
         use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;                 // :603-608
         my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
         if (have) r2[pos] = my_val;
         wg_sync();
         unsigned gmv = 0;                        // which positions of the slice hold a non-zero value
 #pragma unroll
-        for (int k = 0; k < 16; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
+        for (int k = 0; k < NP; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
         nzv = my_val != 0.0;
         m_v = __popc(gmv);
         const int slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
         if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
         wg_sync();
         if (use_round) {
-            const double tot = np_sum16_lds(r3, m_v);
+            const double tot = np_sum_lds<NP>(r3, m_v);
             prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
         }
     }
@@ -754,20 +765,20 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     if (use_round) {
         int acc = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc += sh.cnt[sl][k];
+        for (int k = 0; k < NP; k++) acc += sh.cnt[sl][k];
         const int adj = n_rbs - acc;
         count = prop;
         if (nzv && adj > 0) {
             int rank = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) { const double xk = r2[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+            for (int k = 0; k < NP; k++) { const double xk = r2[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
             count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
         }
     } else {
         // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
         unsigned gmr = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) gmr |= sh.flg[sl][k] != 0 ? (1u << k) : 0u;
+        for (int k = 0; k < NP; k++) gmr |= sh.flg[sl][k] != 0 ? (1u << k) : 0u;
         if (choice != RANENV_INTRA_RR) gmr = 0u;
         int k_sel = __popc(gmr), idx = __popc(gmr & below);
         const bool all = (k_sel == 0);
@@ -782,7 +793,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
     wg_sync();
     int before = 0;                                                                // :464-478 contiguous ranges
 #pragma unroll
-    for (int k = 0; k < 16; k++) before += k < pos ? sh.cnt[sl][k] : 0;
+    for (int k = 0; k < NP; k++) before += k < pos ? sh.cnt[sl][k] : 0;
     rb_start = have ? off + before : 0;
     rb_count = have ? count : 0;
 }
@@ -790,7 +801,7 @@ DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, 
 // The kernel body, instantiated per build (see the kernels behind it): NQ = groups of 8 SE loads in flight per lane;
 // GATHER = the SE gather mode (the tile's per-UE mean from the sidecar, the masked sum by gather_part from the UE-major
 // copy; p.se_pool / p.se_stride then describe that copy) instead of streaming the whole RB-major tile.
-template <int MODE, int NQ, bool GATHER>
+template <int MODE, int NQ, bool GATHER, int NP>
 DEVFN void step_body(const KP &p)
 {
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
@@ -910,7 +921,7 @@ DEVFN void step_body(const KP &p)
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
     if (MODE == MODE_STEP && !pre)
-        alloc_front(p, sh, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
+        alloc_front<NP>(p, sh, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
                     rb_start, rb_count, ST_policy_scores(p));
     RANENV_STAMP(2);
 
@@ -922,6 +933,9 @@ DEVFN void step_body(const KP &p)
 #endif
     };
     if constexpr (GATHER) {
+#if RANENV_GATHER_STATE_FIRST
+        rest_of_state();          // requested ahead of the gather: both latencies run together
+#endif
         if (MODE == MODE_STEP) my_part = gather_part(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
@@ -939,7 +953,8 @@ DEVFN void step_body(const KP &p)
         row_sums(se1, R, [](int) { return false; }, my_full, my_part, hook);
     }
 #if RANENV_DEFER_STATE == 2
-    rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
+    if (!(GATHER && RANENV_GATHER_STATE_FIRST))
+        rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
 #endif
     RANENV_STAMP(3);
     wg_sync();        // every thread is done with the allocation's use of the per-slice rows
@@ -1159,7 +1174,7 @@ DEVFN void step_body(const KP &p)
         const int has_req = si[1], npar = si[6], n = si[2];
         int rbs_s = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) rbs_s += sh.cnt[s][k];
+        for (int k = 0; k < NP; k++) rbs_s += sh.cnt[s][k];
         priority_tab = sh.sf[s][0];
         const double traffic_tab = sh.sf[s][1];
         if (n > 0 && has_req) {                                                    // common.py:343-378
@@ -1167,7 +1182,7 @@ DEVFN void step_body(const KP &p)
             for (int qi = 0; qi < 3; qi++) {
                 if (qi < npar) {
                     const int m = sh.pi[s][2 * qi];
-                    const double mean = np_sum16_lds(srow(sh, s, m), n) / (double)n;
+                    const double mean = np_sum_lds<NP>(srow(sh, s, m), n) / (double)n;
                     sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
                 }
             }
@@ -1181,7 +1196,7 @@ DEVFN void step_body(const KP &p)
             am[m] = undeclared ? 0.0 : 1.0;
             sv[m] = undeclared ? 0.0 : sv[m];
         }
-        const double se_slice = n > 0 ? np_sum16_lds(srow(sh, s, 3), n) / (double)n : 0.0;   // :146-157
+        const double se_slice = n > 0 ? np_sum_lds<NP>(srow(sh, s, 3), n) / (double)n : 0.0;   // :146-157
         const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
         const float tr = (float)(traffic_req / COLD(norm_traffic)), nu = (float)((double)n / COLD(norm_ues));
@@ -1223,7 +1238,7 @@ DEVFN void step_body(const KP &p)
     // ---- player_0 reward (common.py:409-427) ------------------------------------------------------
     int n_neg = 0, n_prio_neg = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < NP; j++) {
         const double ao = xr[0][j], pr = xr[1][j];
         n_neg += (j < S && ao < 0.0) ? 1 : 0;
         n_prio_neg += (j < S && pr * ao < 0.0) ? 1 : 0;
@@ -1244,7 +1259,7 @@ DEVFN void step_body(const KP &p)
     if (my_sel) xr[2][cslot] = my_ao;             // selected entries in slice order (np.mean of a[mask])
     wave_sync();
     if (tid == 0) {
-        double rew = np_sum16_lds(xr[2], m_sel) / (double)m_sel;
+        double rew = np_sum_lds<NP>(xr[2], m_sel) / (double)m_sel;
         if (mode_sel == 1) rew -= 1.0;
         if (COLD(reward)) COLD(reward)[(size_t)e * (S + 1)] = rew;
         // Episode metrics (ranenv_enable_metrics): running sums of what the paper's evaluation reads per TTI
@@ -1285,7 +1300,7 @@ DEVFN void step_body(const KP &p)
     if (late) {
         wg_sync();                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
-        alloc_front(p, sh, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
+        alloc_front<NP>(p, sh, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
                     ns, nc, ST_next_scores(p));
         if (act) { ST_next_rb_start(p)[su] = ns; ST_next_rb_count(p)[su] = nc; }
     }
@@ -1306,20 +1321,21 @@ DEVFN void step_body(const KP &p)
 #else
 #define RANENV_CORE_ATTR
 #endif
-template <int MODE>
-__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p) { step_body<MODE, RANENV_SE_DEPTH, false>(p); }
-template <int MODE>
+template <int MODE, int NP>
+__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p) { step_body<MODE, RANENV_SE_DEPTH, false, NP>(p); }
+template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
 {
-    step_body<MODE, RANENV_SE_DEPTH_SMALL, false>(p);
+    step_body<MODE, RANENV_SE_DEPTH_SMALL, false, NP>(p);
 }
 // The SE gather build (ranenv_set_se_mode): no tile stream, so no queue registers; one build for every batch size.
 #ifndef RANENV_GATHER_WAVES_PER_EU
 #define RANENV_GATHER_WAVES_PER_EU 5
 #endif
-template <int MODE>
+template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_GATHER_WAVES_PER_EU, RANENV_GATHER_WAVES_PER_EU)))
-ranenv_core_kernel_gather(const KP p) { step_body<MODE, 1, true>(p); }
+ranenv_core_kernel_gather(const KP p) { step_body<MODE, 1, true, NP>(p); }
+// Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
 
 // ---------------------------------------------------------------------------------------------
 // Sidecars of the SE pool for the gather mode, built once per bound pool (ranenv_set_se_mode):
@@ -1634,6 +1650,7 @@ struct ranenv {
     int se_mode = RANENV_SE_STREAM;
     double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
+    int np = 16;                                // row width of the step kernel's build: max(S, Us) rounded up to 8, 10 or 16
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
     bool small_batch = false;                   // at most 8 workgroups per CU: the 128-VGPR build with the deeper SE queue
     // ranenv_profile_begin / _end: the dispatch's own start / stop timestamps of every step-kernel launch
@@ -1735,6 +1752,24 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
     return RANENV_OK;
 }
 
+// The build of the step kernel for this handle: SE gather or streaming (lean / small-batch), row width NP.
+template <int MODE, int NP>
+void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
+{
+    if (gather) {
+        if constexpr (MODE != MODE_DENSE) {
+            if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+            else hipLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP>), grid, block, 0, stream, kp);
+        }
+    } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
+        if (h->small_batch) hipExtLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+    } else {
+        if (h->small_batch) hipLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, kp);
+        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, kp);
+    }
+}
+
 // One launch of the step kernel for envs [e0, e0 + n) on `stream` (+ the head kernel when bound).
 template <int MODE>
 hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t stream)
@@ -1760,17 +1795,10 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         ev0 = h->prof_ev[h->prof_used]; ev1 = h->prof_ev[h->prof_used + 1];
         h->prof_used += 2;
     }
-    if (gather) {
-        if constexpr (MODE != MODE_DENSE) {
-            if (ev0) hipExtLaunchKernelGGL(ranenv_core_kernel_gather<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
-            else hipLaunchKernelGGL(ranenv_core_kernel_gather<MODE>, grid, block, 0, stream, kp);
-        }
-    } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
-        if (h->small_batch) hipExtLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
-        else hipExtLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, block, 0, stream, ev0, ev1, 0, kp);
-    } else {
-        if (h->small_batch) hipLaunchKernelGGL(ranenv_core_kernel_small<MODE>, grid, block, 0, stream, kp);
-        else hipLaunchKernelGGL(ranenv_core_kernel<MODE>, grid, block, 0, stream, kp);
+    switch (h->np) {
+    case 8: launch_kernels<MODE, 8>(h, kp, grid, block, stream, ev0, ev1, gather); break;
+    case 10: launch_kernels<MODE, 10>(h, kp, grid, block, stream, ev0, ev1, gather); break;
+    default: launch_kernels<MODE, 16>(h, kp, grid, block, stream, ev0, ev1, gather); break;
     }
     if (kp.head_obs || kp.head_reward) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
     return hipGetLastError();
@@ -1921,13 +1949,18 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     h->nt = (U + WAVE - 1) / WAVE * WAVE;               // step kernel: one lane per UE ...
     if (h->nt < (S * 8 + WAVE - 1) / WAVE * WAVE) h->nt = (S * 8 + WAVE - 1) / WAVE * WAVE;   // ... and per slice-table word
     h->nslot = (S * GRP + WAVE - 1) / WAVE * WAVE;      // head kernel: one lane per slot
+    {
+        const int m = S > Us ? S : Us;
+        h->np = m <= 8 ? 8 : (m <= 10 ? 10 : 16);
+        if (const char *nv = getenv("RANENV_ROW_WIDTH")) { const int v = atoi(nv); if ((v == 8 || v == 10 || v == 16) && v >= m) h->np = v; }   // experiment knob
+    }
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
             h->small_batch = (long long)cfg->batch <= 8ll * prop.multiProcessorCount;
         if (const char *sv = getenv("RANENV_SMALL_BATCH")) h->small_batch = atoi(sv) != 0;   // experiment knob
-        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP>));
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP, 16>));
         if (e != hipSuccess) {
             ranenv_destroy(h);
             return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
