@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the se_gather variant (and its sidecar build)")
     ap.add_argument("--only-gather", action="store_true", help="profiling aid: run the se_gather variant only (the line's value "
                                                                 "is then the gather mode's, labelled so)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="plumbing rehearsal of a multi-rank launch on a box with ONE GPU: every rank uses cuda:0 and the process "
+                         "group is gloo (RCCL refuses two ranks on one device); the line is labelled a rehearsal, not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -243,11 +246,17 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env step has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_on_one_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible: one rank per GPU")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     try:
         wl, label = make_bench_workload(args.config, device, batch=args.batch, n_traces=args.traces,
@@ -262,13 +271,16 @@ def main():
     # of them in a multi-rank run, so there 2 (caller's stream + 1; within 2 % of 3 on one GPU)
     parts = args.partitions if args.partitions is not None else ((3 if world == 1 else 2) if batch >= 2048 else 1)
 
+    coll_dev = torch.device("cpu") if args.rehearse_on_one_gpu else device       # gloo reduces host tensors
+
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=device)
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    gm = (lambda v: gather_metrics(v.cpu())) if args.rehearse_on_one_gpu else gather_metrics
     barrier = dist.barrier if world > 1 else (lambda: None)
     sync = torch.cuda.synchronize
     K = args.steps
@@ -288,12 +300,12 @@ def main():
     times = kms = None
     gathered = None
     if not args.only_gather:
-        gather_metrics(local_metrics(env.reward, env.views(), env.done, 1))   # warm torch's reduction kernels / RCCL
+        gm(local_metrics(env.reward, env.views(), env.done, 1))   # warm torch's reduction kernels / RCCL
         times, kms = rollout_variant()
         # metrics: the only collective, once per reporting interval, outside the timed K steps ...
-        gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
+        gathered = gm(local_metrics(env.reward, env.views(), env.done, K))
         if world > 1:     # ... and one variant with it inside: K steps + the all_gather of the interval's accumulators
-            tg = timed_blocks(lambda: (env.rollout(K), gather_metrics(local_metrics(env.reward, env.views(), env.done, K))),
+            tg = timed_blocks(lambda: (env.rollout(K), gm(local_metrics(env.reward, env.views(), env.done, K))),
                               sync, barrier, max_over_ranks)
             extras["with_metrics_gather"] = dict(block_stats(tg, batch * world * K, K),
                                                  note="the K-step block plus one all_gather of the 8 float64 accumulators per rank")
@@ -372,7 +384,7 @@ def main():
                 extras["se_gather"] = gather_block(env, batch, world, K, tg, kg["step"], kg["n_launches"], parts, pmc)
             if args.only_gather:
                 times, kms = tg, kg
-                gathered = gather_metrics(local_metrics(env.reward, env.views(), env.done, K))
+                gathered = gm(local_metrics(env.reward, env.views(), env.done, K))
             env.set_se_mode("stream")
 
     if rank == 0:
@@ -382,6 +394,8 @@ def main():
                           workload_extra=(", Poisson traffic pool" if args.traffic == "pool"
                                           else ", Poisson traffic drawn on the device (Philox4x32-10)"),
                           extras=extras)
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo: a plumbing check of the multi-rank path, not a scaling measurement"
         if args.only_gather:
             line["config"]["se_mode"] = "gather (profiling aid: value and roofline are the gather mode's, not the headline)"
         if world == 1 and not args.no_cpu_baseline and not args.only_gather:
