@@ -144,7 +144,8 @@ typedef struct {
     int64_t *queue_age_sum;     /* [B][U] buffer_latencies  = queue_age_sum / queue_pkts   */
     int32_t *rb_start;          /* [B][U] sched_decision[u] is ones on [rb_start, +rb_count) */
     int32_t *rb_count;          /* [B][U]                                                  */
-    double  *se_mean;           /* [B][U] mean SE over RBs of the last tile                */
+    double  *se_mean;           /* [B][U] mean SE over RBs of the last tile (of UEs in a slice; for a UE outside every
+                                   slice it is that of the last reset / full-width step: see "compact steps" below) */
     int64_t *win_sent;          /* [B][U] sum of pkt_effective_thr over the <=10-TTI window */
     int64_t *win_dropped;       /* [B][U]                                                  */
     int32_t *step_number;       /* [B]                                                     */
@@ -204,6 +205,18 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dev_sched_decision,
                       const double *dev_traffic_bits, const float *dev_se_tiles,
                       float *dev_obs_inter, float *dev_obs_intra, double *dev_reward, uint8_t *dev_done,
                       void *stream);
+
+/* Compact steps.  A UE outside every slice is allocated nothing and read by no observation; when it also receives no traffic
+ * (MultSliceTraffic.step draws for the UEs of slices with a request only, traffics/mult_slice.py:24-32), stepping it changes
+ * nothing but its 10-TTI window, into which it pushes zeros.  ranenv_step / _step_range / _step_part / _rollout therefore
+ * step only the UEs that are in a slice (the kernel's lanes are ordered slice members first; waves without one leave at
+ * once) whenever that is exact: the traffic comes from the device generator, or from a traffic pool that the library has
+ * examined (once per change of pool, scenarios, episodes or episode table: a kernel over the traces, one read-back at the next
+ * step) and found empty for every idle UE; and no earlier step can have given an idle UE packets (explicit dev_traffic_bits
+ * and dense steps switch compact steps off until the next ranenv_reset of the whole batch).  A UE that comes back into a
+ * slice (a reset into another scenario) first makes up for the zero pushes its window missed.  Results are identical to
+ * full-width steps; the one visible difference is views.se_mean of idle UEs.  Call ranenv_set_episodes again after changing
+ * a bound traffic pool's contents. */
 
 /* The same TTI for the envs [env_first, env_first + env_count) only, enqueued on `stream` and nothing else: no batch
  * partitions, no joins.  All array arguments are the whole-batch arrays of ranenv_step (indexed by env).  This is the

@@ -67,19 +67,21 @@ struct Tables {  // scenario pool on the device, rows of [n_scenarios]
     int32_t *slice_ues;  // [NS][S][Us]
     int32_t *slot;       // [3][NS][S*16] slot_ue (UE id, -1 = empty slot), slot_mp, slot_pk (its max_pkts / pkt_size)
     int32_t *slice_usecase;                 // [NS][S] SchedColORAN: bit 0 eMBB, bit 1 URLLC
-    int32_t *ue;         // [5][NS][U] ue_slice, ue_pos, ue_pkt_size, ue_max_pkts, ue_max_age
+    int32_t *ue;         // [6][NS][U] ue_slice, ue_pos, ue_pkt_size, ue_max_pkts, ue_max_age, lane_ue -- all in LANE order: lane l
+                         // of the step kernel owns UE lane_ue[l]; a scenario's UEs in slices come first (ascending UE id),
+                         // the idle ones behind them, so that the waves beyond the last UE in a slice have nothing to step
 };
 
 struct State {
-    int32_t *u4;         // [12][B][U] 4-byte per-UE fields (the ST_* accessors below name them)
+    int32_t *u4;         // [13][B][U] 4-byte per-UE fields (the ST_* accessors below name them)
     int64_t *u8;         // [4][B][U]  8-byte per-UE fields: queue_age_sum, win_sent, win_dropped (int64), se_mean (double)
-    int32_t *b4;         // [8][B]     per-env counters
+    int32_t *b4;         // [10][B]    per-env counters
     int2 *age_ring; int32_t *ring_sent; int32_t *ring_drop;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
     double *next_scores; // with next_rb_start / next_rb_count: the allocation made at the end of a step for the next one
                          // (device policy), valid while alloc_gen[e] == KP::alloc_gen
 };
-enum { N_U4 = 12, N_U8 = 4, N_B4 = 8 };
+enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 6 };
 #define ST_queue_pkts(p) ((p).st.u4 + (size_t)(0) * (size_t)(p).BU)
 #define ST_front(p) ((p).st.u4 + (size_t)(1) * (size_t)(p).BU)
 #define ST_front_rem(p) ((p).st.u4 + (size_t)(2) * (size_t)(p).BU)
@@ -92,6 +94,7 @@ enum { N_U4 = 12, N_U8 = 4, N_B4 = 8 };
 #define ST_rb_count(p) ((p).st.u4 + (size_t)(9) * (size_t)(p).BU)
 #define ST_next_rb_start(p) ((p).st.u4 + (size_t)(10) * (size_t)(p).BU)
 #define ST_next_rb_count(p) ((p).st.u4 + (size_t)(11) * (size_t)(p).BU)
+#define ST_last_push(p) ((p).st.u4 + (size_t)(12) * (size_t)(p).BU)
 #define ST_queue_age_sum(p) ((int64_t *)((p).st.u8 + (size_t)(0) * (size_t)(p).BU))
 #define ST_win_sent(p) ((int64_t *)((p).st.u8 + (size_t)(1) * (size_t)(p).BU))
 #define ST_win_dropped(p) ((int64_t *)((p).st.u8 + (size_t)(2) * (size_t)(p).BU))
@@ -104,6 +107,8 @@ enum { N_U4 = 12, N_U8 = 4, N_B4 = 8 };
 #define ST_alloc_gen(p) ((p).st.b4 + (size_t)(5) * (size_t)(p).B)
 #define ST_episode_no(p) ((p).st.b4 + (size_t)(6) * (size_t)(p).B)
 #define ST_reset_count(p) ((p).st.b4 + (size_t)(7) * (size_t)(p).B)
+#define ST_push_total(p) ((p).st.b4 + (size_t)(8) * (size_t)(p).B)
+#define ST_clear_mark(p) ((p).st.b4 + (size_t)(9) * (size_t)(p).B)
 #define ST_age_ring(p) ((p).st.age_ring)
 #define ST_ring_sent(p) ((p).st.ring_sent)
 #define ST_ring_drop(p) ((p).st.ring_drop)
@@ -116,6 +121,7 @@ enum { N_U4 = 12, N_U8 = 4, N_B4 = 8 };
 #define TB_ue_pkt_size(p) ((p).tab.ue + (size_t)(2) * (size_t)(p).NSU)
 #define TB_ue_max_pkts(p) ((p).tab.ue + (size_t)(3) * (size_t)(p).NSU)
 #define TB_ue_max_age(p) ((p).tab.ue + (size_t)(4) * (size_t)(p).NSU)
+#define TB_lane_ue(p) ((p).tab.ue + (size_t)(5) * (size_t)(p).NSU)
 #define TB_slot_ue(p) ((p).tab.slot + (size_t)(0) * (size_t)(p).NSL)
 #define TB_slot_mp(p) ((p).tab.slot + (size_t)(1) * (size_t)(p).NSL)
 #define TB_slot_pk(p) ((p).tab.slot + (size_t)(2) * (size_t)(p).NSL)
@@ -131,6 +137,8 @@ struct KP {
     long long BU, NSU, NSL;   // slab strides: B*U, n_scenarios*U, n_scenarios*S*16
     int e0;   // first env of this launch
     int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
+    int compact;     // step only the UEs that are in a slice (lanes are ordered slice members first): waves without one leave
+                     // at once.  Set by the host when it is exact: UEs outside every slice get no traffic (see idle_traffic_ok)
     int late;        // 0: every step allocates at its head; 1: a hashed half of the envs, 2: all envs allocate for the next
                      // TTI at the end of the step (device policy only), so that heads and tails of workgroups differ in
                      // what they load the CU with
@@ -854,11 +862,24 @@ DEVFN void step_body(const KP &p)
 
     // ---- loads, in the order they are needed: memory operations retire in issue order (vmcnt), so what the
     // allocation waits for (tables, UE state) is issued before the SE tile and does not queue behind it
-    const bool act = tid < U;
-    const int u = act ? tid : U - 1;
-    const size_t su = (size_t)e * U + u, tu = (size_t)sc * U + u;
+    // Lane l owns UE lane_ue[l] of its scenario: the UEs that are in a slice first, the idle ones behind (the tables are
+    // stored in that order).  A step in compact mode touches slice members only: a UE outside every slice receives no
+    // traffic (the host made sure, idle_traffic_ok), is allocated nothing and is read by no observation, so its state
+    // stays what the last reset left; the pushes its 10-TTI window misses meanwhile are made up for when it is stepped
+    // again (catch-up below).  Waves that hold no slice member leave before the first barrier: at the headline size 76 %
+    // of the scenarios have at most 64 UEs in slices, and their envs run one wave instead of two.
+    const int lane = tid < U ? tid : U - 1;
+    const size_t tu = (size_t)sc * U + lane;
+    const int u = TB_lane_ue(p)[tu];
     const int slc = TB_ue_slice(p)[tu], ue_pos = TB_ue_pos(p)[tu];
     const int pkt_size = TB_ue_pkt_size(p)[tu], max_pkts = TB_ue_max_pkts(p)[tu], max_age = TB_ue_max_age(p)[tu];
+    const bool compact = MODE == MODE_STEP && p.compact != 0;
+    const bool act = tid < U && !(compact && slc < 0);
+    if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return;     // (wave 0 stays: it runs the slice roles)
+    const size_t su = (size_t)e * U + u;
+    const int ptot = uni(ST_push_total(p)[e]);      // window pushes of this env so far (wraps; only differences are used)
+    const int cmark = uni(ST_clear_mark(p)[e]);     // index of the first push behind the last clearing of the window
+    int lastp = ptot;                               // index behind this UE's last push
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     double sem_prev = 0.0;
@@ -874,7 +895,7 @@ DEVFN void step_body(const KP &p)
             sum_age = ST_queue_age_sum(p)[su];
             front = ST_front(p)[su]; front_rem = ST_front_rem(p)[su]; fifo = ST_fifo(p)[su];
         }
-        if (!clear_hist) win_drop = ST_win_dropped(p)[su];
+        if (!clear_hist) { win_drop = ST_win_dropped(p)[su]; lastp = ST_last_push(p)[su]; }
         if (hlen == D) { old_s = *rs; old_d = *rd; }
         if (MODE != MODE_RESET && !gen_traffic)
             traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
@@ -885,12 +906,16 @@ DEVFN void step_body(const KP &p)
     if (MODE == MODE_STEP) sem_prev = ST_se_mean(p)[su];
     double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
     if (GATHER) sem_tile = p.se_mean_pool[(size_t)tile_no * U + u];
-    // the scenario's slice tables, one element per thread (blockDim >= 8*S), parked in LDS below
-    int st_si = 0, st_pi = 0; double st_pf = 0.0, st_sf = 0.0;
-    if (tid < S * 8) st_si = TB_slice_i32(p)[(size_t)sc * S * 8 + tid];
-    if (tid < S * 6) st_pi = TB_param_i32(p)[(size_t)sc * S * 6 + tid];
-    if (tid < S * 3) st_pf = TB_param_f64(p)[(size_t)sc * S * 3 + tid];
-    if (tid < S * 2) st_sf = TB_slice_f64(p)[(size_t)sc * S * 2 + tid];
+    // the scenario's slice tables, parked in LDS below by wave 0 (the other waves may have left): up to two words per lane
+    int st_si0 = 0, st_si1 = 0, st_pi0 = 0, st_pi1 = 0; double st_pf = 0.0, st_sf = 0.0;
+    if (tid < WAVE) {
+        if (tid < S * 8) st_si0 = TB_slice_i32(p)[(size_t)sc * S * 8 + tid];
+        if (tid + WAVE < S * 8) st_si1 = TB_slice_i32(p)[(size_t)sc * S * 8 + tid + WAVE];
+        if (tid < S * 6) st_pi0 = TB_param_i32(p)[(size_t)sc * S * 6 + tid];
+        if (tid + WAVE < S * 6) st_pi1 = TB_param_i32(p)[(size_t)sc * S * 6 + tid + WAVE];
+        if (tid < S * 3) st_pf = TB_param_f64(p)[(size_t)sc * S * 3 + tid];
+        if (tid < S * 2) st_sf = TB_slice_f64(p)[(size_t)sc * S * 2 + tid];
+    }
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
     if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
@@ -908,14 +933,20 @@ DEVFN void step_body(const KP &p)
     SeStream<GATHER ? 1 : NQ> se1;
     if (!GATHER) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
-    // zero the per-slice rows, park the tables
-    for (int i = tid; i < GRP * (4 * GRP + 2); i += (int)blockDim.x) (&sh.rows[0][0])[i] = 0.0;
-    for (int i = tid; i < GRP * (GRP + 4); i += (int)blockDim.x) (&sh.cnt[0][0])[i] = 0;
-    for (int i = tid; i < GRP * (GRP + 4) / 4; i += (int)blockDim.x) reinterpret_cast<int *>(&sh.flg[0][0])[i] = 0;
-    if (tid < S * 8) (&sh.si[0][0])[tid] = st_si;
-    if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi;
-    if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
-    if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
+    // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables
+    if (tid < WAVE) {
+        for (int i = tid; i < S * 4 * NP; i += WAVE) {
+            const int sl0 = i / (4 * NP), rem = i - sl0 * (4 * NP), k0 = rem / NP, j0 = rem - k0 * NP;
+            sh.rows[sl0][k0 * GRP + j0] = 0.0;
+        }
+        for (int i = tid; i < S * NP; i += WAVE) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; sh.flg[sl0][j0] = 0; }
+        if (tid < S * 8) (&sh.si[0][0])[tid] = st_si0;
+        if (tid + WAVE < S * 8) (&sh.si[0][0])[tid + WAVE] = st_si1;
+        if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi0;
+        if (tid + WAVE < S * 6) (&sh.pi[0][0])[tid + WAVE] = st_pi1;
+        if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
+        if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
+    }
     wg_sync();
     RANENV_STAMP(1);
 
@@ -1046,9 +1077,23 @@ DEVFN void step_body(const KP &p)
             }
             fifo = head | (nent << 16);
         }
+        // A UE that was not stepped for a while (outside every slice, compact mode) missed the pushes [lastp, ptot): each
+        // would have pushed zeros.  Made up for here, oldest first; only the last D matter.  A push at index q finds the
+        // window min(D, q - cmark) long, and only a full window gives up what its slot holds.  (Empty in the steady state.)
+        if (!clear_hist && lastp != ptot) {
+            int q = ptot - lastp > D ? ptot - D : lastp;
+            if (ptot - q == D) { old_s = 0; old_d = 0; }         // the slot of this push is among them: it will hold a zero
+            for (; q != ptot; q++) {
+                int slot = npush - (ptot - q); slot += slot < 0 ? D : 0;
+                int32_t *qs = ST_ring_sent(p) + ((size_t)e * D + slot) * U + u, *qd = ST_ring_drop(p) + ((size_t)e * D + slot) * U + u;
+                if (q - cmark >= D) { win_sent -= *qs; win_drop -= *qd; }
+                *qs = 0; *qd = 0;
+            }
+        }
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
         win_sent += sent - old_s; win_drop += dropped - old_d;
         *rs = (int32_t)sent; *rd = (int32_t)dropped;
+        ST_last_push(p)[su] = ptot + 1;
         ST_queue_pkts(p)[su] = total; ST_queue_age_sum(p)[su] = sum_age;
         ST_front(p)[su] = front; ST_front_rem(p)[su] = front_rem; ST_fifo(p)[su] = fifo;
         ST_win_sent(p)[su] = win_sent; ST_win_dropped(p)[su] = win_drop;
@@ -1153,6 +1198,7 @@ DEVFN void step_body(const KP &p)
 #endif
         if (tid == 0) {
             ST_step_no(p)[e] = (MODE == MODE_RESET) ? 0 : t + 1; ST_hist_len(p)[e] = hlen_new; ST_n_push(p)[e] = npush + 1 == D ? 0 : npush + 1;
+            ST_push_total(p)[e] = ptot + 1;
             ST_se_pos(p)[e] = (MODE == MODE_RESET) ? ep.se_offset : (se_pos + 1 >= ep.se_len ? 0 : se_pos + 1);
             ST_trf_pos(p)[e] = (MODE == MODE_RESET) ? ep.trf_offset : (trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1);
         }
@@ -1280,6 +1326,11 @@ DEVFN void step_body(const KP &p)
         ST_step_no(p)[e] = step_new;
         ST_hist_len(p)[e] = hlen_new;
         ST_n_push(p)[e] = npush + 1 == D ? 0 : npush + 1;
+        ST_push_total(p)[e] = ptot + 1;
+        // the first push of the current window era; kept within 2 D of the counter, which is as good as exact (a window is
+        // full after D pushes) and survives the counter's wrap-around
+        if (clear_hist) ST_clear_mark(p)[e] = ptot;
+        else if (ptot + 1 - cmark > 2 * D) ST_clear_mark(p)[e] = ptot + 1 - 2 * D;
         if (MODE == MODE_RESET) { ST_se_pos(p)[e] = ep.se_offset; ST_trf_pos(p)[e] = ep.trf_offset; }
         else {
             ST_se_pos(p)[e] = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
@@ -1624,6 +1675,25 @@ __global__ void __launch_bounds__(64) ranenv_advance_kernel(const AdvanceArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Do the traffic traces carry bits for UEs outside every slice?  (MultSliceTraffic.step never does: it draws for the UEs
+// of slices with a request only, traffics/mult_slice.py:24-32.)  One workgroup per episode descriptor scans the rows of
+// its traffic trace at the idle UEs of its scenario.  Only when none does may a step leave idle UEs alone (KP::compact).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ranenv_idle_traffic_kernel(const ranenv_episode *eps, const int32_t *pool, int U,
+                                                                  const int32_t *lane_slice, const int32_t *lane_ue, int *violations)
+{
+    const ranenv_episode ep = eps[blockIdx.x];
+    int bad = 0;
+    for (int l = threadIdx.x; l < U; l += (int)blockDim.x) {
+        const size_t tu = (size_t)ep.scenario * U + l;
+        if (lane_slice[tu] >= 0) continue;
+        const int ue = lane_ue[tu];
+        for (int row = 0; row < ep.trf_len; row++) bad |= pool[((size_t)ep.trf_base + (size_t)row) * U + ue] != 0;
+    }
+    if (bad) atomicOr(violations, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
@@ -1649,6 +1719,10 @@ struct ranenv {
     // SE gather mode (ranenv_set_se_mode): sidecars of the bound pool, owned by the handle
     int se_mode = RANENV_SE_STREAM;
     double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
+    // compact steps (KP::compact): allowed while UEs outside every slice provably receive no traffic
+    bool compact_enabled = true, idle_check_dirty = true, pool_idle_zero = false, table_idle_zero = false;
+    bool idle_state_clean = true;               // no step so far can have given an idle UE packets (else: full width until a full reset)
+    int *d_violations = nullptr;
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int np = 16;                                // row width of the step kernel's build: max(S, Us) rounded up to 8, 10 or 16
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
@@ -1804,6 +1878,40 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     return hipGetLastError();
 }
 
+// May the step that `kp` describes leave the UEs outside every slice alone?  Yes when they get no traffic: the device
+// generator never draws for them; a traffic pool is examined once per change of pools / scenarios / episodes (a kernel over
+// the episode descriptors and, with auto-reset, over the episode table, then one read-back); explicit per-step traffic is
+// not examined at all (full width).
+int compact_for(ranenv_handle h, const KP &kp, hipStream_t stream, int *out)
+{
+    *out = 0;
+    // a step that may hand idle UEs packets (explicit traffic, an unexamined or offending pool) leaves them with queues that
+    // only full-width steps keep ageing: compact steps stay off until a reset of the whole batch
+    if (kp.traffic_bits != nullptr || kp.dense != nullptr) { h->idle_state_clean = false; return RANENV_OK; }
+    if (kp.trf_gen) { *out = (h->compact_enabled && h->idle_state_clean) ? 1 : 0; return RANENV_OK; }
+    if (!kp.trf_pool) return RANENV_OK;
+    if (!h->compact_enabled) return RANENV_OK;
+    if (h->idle_check_dirty) {
+        if (!h->d_violations && dev_alloc(h, &h->d_violations, 2) != RANENV_OK) return RANENV_E_NOMEM;
+        HIP_TRY(h, hipMemsetAsync(h->d_violations, 0, 2 * sizeof(int), stream));
+        const int U = h->cfg.n_ues;
+        hipLaunchKernelGGL(ranenv_idle_traffic_kernel, dim3((unsigned)h->cfg.batch), dim3(256), 0, stream, h->d_episodes, kp.trf_pool, U,
+                           TB_ue_slice(h->kp), TB_lane_ue(h->kp), h->d_violations);
+        if (h->d_ep_table)
+            hipLaunchKernelGGL(ranenv_idle_traffic_kernel, dim3((unsigned)h->ep_table_n), dim3(256), 0, stream, h->d_ep_table, kp.trf_pool, U,
+                               TB_ue_slice(h->kp), TB_lane_ue(h->kp), h->d_violations + 1);
+        int v[2] = {1, 1};
+        HIP_TRY(h, hipMemcpyAsync(v, h->d_violations, sizeof(v), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        h->pool_idle_zero = v[0] == 0; h->table_idle_zero = h->d_ep_table ? v[1] == 0 : true;
+        h->idle_check_dirty = false;
+    }
+    const bool zero = h->pool_idle_zero && (!h->ar_on || h->table_idle_zero);
+    if (!zero) h->idle_state_clean = false;
+    *out = (zero && h->compact_enabled && h->idle_state_clean) ? 1 : 0;
+    return RANENV_OK;
+}
+
 // One TTI of the whole batch.  Without partitions: one launch on the caller's stream.  With partitions: one launch
 // per partition on the partition's own stream; `join_in` orders them behind what the caller's stream holds so far
 // (inputs), `join_out` orders the caller's stream behind them (outputs).  ranenv_rollout enqueues n TTIs with a join
@@ -1927,6 +2035,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.L = (int)L; kp.max_steps = cfg->max_steps; kp.flags = cfg->flags;
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
     kp.late = RANENV_LATE_DEFAULT;
+    if (const char *cv = getenv("RANENV_COMPACT")) h->compact_enabled = atoi(cv) != 0;                     // experiment knob
     if (const char *lv = getenv("RANENV_LATE")) kp.late = atoi(lv) < 0 ? 0 : (atoi(lv) > 2 ? 2 : atoi(lv));   // experiment knob
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
     kp.norm_traffic = cfg->norm_traffic; kp.norm_ues = cfg->norm_ues; kp.norm_se = cfg->norm_se;
@@ -1937,7 +2046,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.tab.slice_i32, NS * S * 8); ALLOC(kp.tab.slice_f64, NS * S * 2);
     ALLOC(kp.tab.param_i32, NS * S * 6); ALLOC(kp.tab.param_f64, NS * S * 3);
     ALLOC(kp.tab.slice_ues, NS * S * Us); ALLOC(kp.tab.slice_usecase, NS * S);
-    ALLOC(kp.tab.ue, 5 * NS * U); ALLOC(kp.tab.slot, 3 * NS * NSL);
+    ALLOC(kp.tab.ue, (size_t)N_TUE * NS * U); ALLOC(kp.tab.slot, 3 * NS * NSL);
     ALLOC(kp.st.u4, (size_t)N_U4 * B * U); ALLOC(kp.st.u8, (size_t)N_U8 * B * U); ALLOC(kp.st.b4, (size_t)N_B4 * B);
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
@@ -2040,6 +2149,21 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
                     return fail(h, RANENV_E_INVALID, "scenario %zu: ue_slice/ue_pos disagree with slice_ues", i);
                 sue[o] = ue; smp[o] = t->ue_max_pkts[i * U + ue]; spk[o] = t->ue_pkt_size[i * U + ue];
             }
+    // per-UE tables in lane order: a scenario's UEs in slices first (ascending UE id), the idle ones behind
+    std::vector<int32_t> lt[N_TUE];
+    for (auto &v : lt) v.resize(n * (size_t)U);
+    for (size_t i = 0; i < n; i++) {
+        int l = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int ue = 0; ue < U; ue++) {
+                const size_t o = i * U + ue;
+                if ((t->ue_slice[o] >= 0) != (pass == 0)) continue;
+                const size_t d = i * U + (size_t)l++;
+                lt[0][d] = t->ue_slice[o]; lt[1][d] = t->ue_pos[o]; lt[2][d] = t->ue_pkt_size[o];
+                lt[3][d] = t->ue_max_pkts[o]; lt[4][d] = t->ue_max_age[o]; lt[5][d] = ue;
+            }
+    }
+    h->idle_check_dirty = true;                 // which UEs are idle changed: traffic traces are re-examined before compact steps
     const size_t f = (size_t)first;
     const Tables &d = h->kp.tab;
     const KP &k = h->kp;
@@ -2049,11 +2173,12 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     PUT(d.param_i32 + f * S * 6, pi.data(), n * S * 6, int32_t);
     PUT(d.param_f64 + f * S * 3, pf.data(), n * S * 3, double);
     PUT(d.slice_ues + f * S * Us, t->slice_ues, n * S * Us, int32_t);
-    PUT(TB_ue_slice(k) + f * U, t->ue_slice, n * U, int32_t);
-    PUT(TB_ue_pos(k) + f * U, t->ue_pos, n * U, int32_t);
-    PUT(TB_ue_pkt_size(k) + f * U, t->ue_pkt_size, n * U, int32_t);
-    PUT(TB_ue_max_pkts(k) + f * U, t->ue_max_pkts, n * U, int32_t);
-    PUT(TB_ue_max_age(k) + f * U, t->ue_max_age, n * U, int32_t);
+    PUT(TB_ue_slice(k) + f * U, lt[0].data(), n * U, int32_t);
+    PUT(TB_ue_pos(k) + f * U, lt[1].data(), n * U, int32_t);
+    PUT(TB_ue_pkt_size(k) + f * U, lt[2].data(), n * U, int32_t);
+    PUT(TB_ue_max_pkts(k) + f * U, lt[3].data(), n * U, int32_t);
+    PUT(TB_ue_max_age(k) + f * U, lt[4].data(), n * U, int32_t);
+    PUT(TB_lane_ue(k) + f * U, lt[5].data(), n * U, int32_t);
     PUT(TB_slot_ue(k) + f * NSL, sue.data(), n * NSL, int32_t);
     PUT(TB_slot_mp(k) + f * NSL, smp.data(), n * NSL, int32_t);
     PUT(TB_slot_pk(k) + f * NSL, spk.data(), n * NSL, int32_t);
@@ -2086,7 +2211,7 @@ int ranenv_bind_traffic_pool(ranenv_handle h, const int32_t *dev_pool, int64_t n
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     if (dev_pool != nullptr && n_rows < 1) return fail(h, RANENV_E_INVALID, "traffic pool needs n_rows >= 1");
     h->kp.trf_pool = dev_pool; h->trf_rows_n = dev_pool ? n_rows : 0;
-    h->have_episodes = false;
+    h->have_episodes = false; h->idle_check_dirty = true;
     return RANENV_OK;
 }
 
@@ -2108,7 +2233,7 @@ int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *eps, void *stream
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(h->d_episodes, eps, sizeof(ranenv_episode) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
-    h->have_episodes = true; h->alloc_gen++;
+    h->have_episodes = true; h->alloc_gen++; h->idle_check_dirty = true;
     return RANENV_OK;
 }
 
@@ -2144,6 +2269,7 @@ int ranenv_reset(ranenv_handle h, const uint8_t *env_mask, const float *se_tiles
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = nullptr;
     hipError_t e = launch<MODE_RESET>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "reset launch: %s", hipGetErrorString(e));
+    if (env_mask == nullptr) h->idle_state_clean = true;        // every queue of the batch is empty again
     return RANENV_OK;
 }
 
@@ -2157,6 +2283,8 @@ int ranenv_step(ranenv_handle h, const double *scores, const uint8_t *intra, con
     KP kp = h->kp;
     kp.env_mask = nullptr; kp.se_tiles = se_tiles; kp.scores = scores; kp.intra = intra; kp.traffic_bits = traffic_bits;
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
+    rc = compact_for(h, kp, (hipStream_t)stream, &kp.compact);
+    if (rc != RANENV_OK) return rc;
     hipError_t e = launch<MODE_STEP>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "step launch: %s", hipGetErrorString(e));
     return RANENV_OK;
@@ -2172,6 +2300,7 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     KP kp = h->kp;
     kp.env_mask = nullptr; kp.se_tiles = se_tiles; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = traffic_bits;
     kp.dense = dense; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
+    h->idle_state_clean = false;                 // (a dense decision is the facade's path: explicit traffic, any UE)
     hipError_t e = launch<MODE_DENSE>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "dense step launch: %s", hipGetErrorString(e));
     return RANENV_OK;
@@ -2191,6 +2320,8 @@ int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count, con
     kp.env_mask = nullptr; kp.se_tiles = se_tiles; kp.scores = scores; kp.intra = intra; kp.traffic_bits = traffic_bits;
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     finalize_kp(h, kp);
+    rc = compact_for(h, kp, (hipStream_t)stream, &kp.compact);
+    if (rc != RANENV_OK) return rc;
     hipError_t e = launch_range<MODE_STEP>(h, kp, env_first, env_count, (hipStream_t)stream);
     if (e == hipSuccess && (h->cfg.flags & RANENV_F_SYNC_CHECK)) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "step launch (envs [%d,%d)): %s", env_first, env_first + env_count, hipGetErrorString(e));
@@ -2358,6 +2489,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     hipStream_t stream = (hipStream_t)stream_;
     finalize_kp(h, kp);
+    rc = compact_for(h, kp, stream, &kp.compact);
+    if (rc != RANENV_OK) return rc;
     // With auto-reset on, an env whose episode ends inside the rollout moves on to its next episode without the host:
     // the advance kernel + the step kernel in RESET mode follow that TTI's step on the partition's stream.  They are only
     // enqueued for TTIs at which some env of the partition finishes: the step counters are read once here and followed
@@ -2371,7 +2504,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
         HIP_TRY(h, hipStreamSynchronize(stream));
         HIP_TRY(h, hipMemcpy(steps.data(), ST_step_no(h->kp), sizeof(int32_t) * steps.size(), hipMemcpyDeviceToHost));
         adv = advance_args(h, done, obs_inter, obs_intra, nullptr, nullptr, nullptr);
-        kpr.env_mask = h->d_ar_mask; kpr.reward = nullptr; kpr.done = nullptr;
+        kpr.env_mask = h->d_ar_mask; kpr.reward = nullptr; kpr.done = nullptr; kpr.compact = 0;
         kpr.head_reward = nullptr;               // the terminal transition's head rewards stay, like reward / done
     }
     const bool follow = h->ar_on;
@@ -2489,7 +2622,7 @@ int ranenv_set_episode_table(ranenv_handle h, const ranenv_episode *host_table, 
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(d, host_table, sizeof(ranenv_episode) * (size_t)n_episodes, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
-    h->d_ep_table = d; h->ep_table_first = first_episode; h->ep_table_n = n_episodes;
+    h->d_ep_table = d; h->ep_table_first = first_episode; h->ep_table_n = n_episodes; h->idle_check_dirty = true;
     h->ar_on = false;                      // the rule is re-validated against the new table
     return RANENV_OK;
 }
