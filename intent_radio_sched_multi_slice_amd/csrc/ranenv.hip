@@ -67,9 +67,10 @@ struct Tables {  // scenario pool on the device, rows of [n_scenarios]
     int32_t *slice_ues;  // [NS][S][Us]
     int32_t *slot;       // [3][NS][S*16] slot_ue (UE id, -1 = empty slot), slot_mp, slot_pk (its max_pkts / pkt_size)
     int32_t *slice_usecase;                 // [NS][S] SchedColORAN: bit 0 eMBB, bit 1 URLLC
-    int32_t *ue;         // [6][NS][U] ue_slice, ue_pos, ue_pkt_size, ue_max_pkts, ue_max_age, lane_ue -- all in LANE order: lane l
-                         // of the step kernel owns UE lane_ue[l]; a scenario's UEs in slices come first (ascending UE id),
-                         // the idle ones behind them, so that the waves beyond the last UE in a slice have nothing to step
+    int32_t *ue;         // [2][6][NS][U] ue_slice, ue_pos, ue_pkt_size, ue_max_pkts, ue_max_age, lane_ue -- all in LANE order: lane l
+                         // of the step kernel owns UE lane_ue[l].  Set 0 (compact steps): a scenario's UEs in slices first
+                         // (ascending UE id), the idle ones behind them, so that the waves beyond the last UE in a slice have
+                         // nothing to step.  Set 1 (full-width launches): lane l = UE l, the coalesced order for the SE stream
 };
 
 struct State {
@@ -81,7 +82,7 @@ struct State {
     double *next_scores; // with next_rb_start / next_rb_count: the allocation made at the end of a step for the next one
                          // (device policy), valid while alloc_gen[e] == KP::alloc_gen
 };
-enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 6 };
+enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 12 };
 #define ST_queue_pkts(p) ((p).st.u4 + (size_t)(0) * (size_t)(p).BU)
 #define ST_front(p) ((p).st.u4 + (size_t)(1) * (size_t)(p).BU)
 #define ST_front_rem(p) ((p).st.u4 + (size_t)(2) * (size_t)(p).BU)
@@ -553,7 +554,7 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
 #if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of thread 0 at up to S phase boundaries of the step
                           kernel, dumped into policy_scores[e][k] instead of the scores (tools/stamps.py) */
 #define RANENV_STAMP(k) do { if (threadIdx.x == 0 && (k) < p.S) \
-    ST_policy_scores(p)[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+    ST_policy_scores(p)[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RANENV_STAMP(k) do { } while (0)
 #endif
@@ -578,18 +579,20 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
 // =============================================================================================
 constexpr int CORE_NT = GRP * GRP;   // 256 = largest U
 
+template <int NP>           // row width of the build: S <= NP slices, <= NP UEs per slice
 struct SharedCore {
-    // per slice 4 rows of 16 doubles by UE position: allocation scratch, then drift x3 + mean SE for (3).  The lanes of
-    // a wave belong to different slices and read the same position of their own slice's row: the 2-double pad puts
-    // the slices 4 banks apart instead of on one bank (16-byte alignment of the rows kept for 128-bit LDS reads)
-    double rows[GRP][4 * GRP + 2];
+    // per slice 4 rows of NP doubles by UE position: allocation scratch, then drift x3 + mean SE for (3).  The lanes of
+    // a wave belong to different slices and read the same position of their own slice's row: the 2-double pad keeps
+    // the slices off one bank (16-byte alignment of the rows kept for 128-bit LDS reads).  Sized by NP, not by 16: with one
+    // wave per env (compact steps) it is LDS that caps the workgroups of a CU -- 5.6 KB instead of 12.2 KB at NP = 10
+    double rows[NP][4 * NP + 2];
     double xr[4][GRP];            // cross-slice rows
-    double pf[GRP][3];            // param value                     } slice tables of this env's scenario
-    double sf[GRP][2];            // priority, traffic               }
-    int si[GRP][8];               // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
-    int pi[GRP][6];               // (metric, op) x 3
-    int cnt[GRP][GRP + 4];        // RBs of each slot (padded like rows)
-    unsigned char flg[GRP][GRP + 4];   // buffer-not-empty flag of each slot (bytes: the struct stays below 12.5 KB, 12 workgroups' worth per CU)
+    double pf[NP][3];             // param value                     } slice tables of this env's scenario
+    double sf[NP][2];             // priority, traffic               }
+    int si[NP][8];                // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
+    int pi[NP][6];                // (metric, op) x 3
+    int cnt[NP][NP + 4];          // RBs of each slot (padded like rows)
+    unsigned char flg[NP][NP + 6];    // buffer-not-empty flag of each slot
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
 };
 
@@ -609,14 +612,14 @@ DEVFN void wg_sync()
 #endif
 }
 
-DEVFN double *srow(SharedCore &sh, int s, int k) { return &sh.rows[s][k * GRP]; }
+template <int NP> DEVFN double *srow(SharedCore<NP> &sh, int s, int k) { return &sh.rows[s][k * NP]; }
 
 // Role (0).  Called by every thread of the workgroup (it contains barriers); `have` = this thread's UE is
 // in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
 // in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
 // slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
 template <int NP>
-DEVFN void alloc_front(const KP &p, SharedCore &sh, int e, int hlen, bool have, int slc, int pos,
+DEVFN void alloc_front(const KP &p, SharedCore<NP> &sh, int e, int hlen, bool have, int slc, int pos,
                        int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out)
 {
     auto &xs = sh.xr;
@@ -813,7 +816,7 @@ template <int MODE, int NQ, bool GATHER, int NP>
 DEVFN void step_body(const KP &p)
 {
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
-    __shared__ SharedCore sh;
+    __shared__ SharedCore<NP> sh;
     auto &xr = sh.xr;
     const int e = p.e0 + blockIdx.x;
     const int tid = threadIdx.x;
@@ -868,12 +871,12 @@ DEVFN void step_body(const KP &p)
     // stays what the last reset left; the pushes its 10-TTI window misses meanwhile are made up for when it is stepped
     // again (catch-up below).  Waves that hold no slice member leave before the first barrier: at the headline size 76 %
     // of the scenarios have at most 64 UEs in slices, and their envs run one wave instead of two.
+    const bool compact = MODE == MODE_STEP && p.compact != 0;
     const int lane = tid < U ? tid : U - 1;
-    const size_t tu = (size_t)sc * U + lane;
+    const size_t tu = (size_t)sc * U + lane + (compact ? (size_t)0 : (size_t)6 * (size_t)p.NSU);
     const int u = TB_lane_ue(p)[tu];
     const int slc = TB_ue_slice(p)[tu], ue_pos = TB_ue_pos(p)[tu];
     const int pkt_size = TB_ue_pkt_size(p)[tu], max_pkts = TB_ue_max_pkts(p)[tu], max_age = TB_ue_max_age(p)[tu];
-    const bool compact = MODE == MODE_STEP && p.compact != 0;
     const bool act = tid < U && !(compact && slc < 0);
     if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return;     // (wave 0 stays: it runs the slice roles)
     const size_t su = (size_t)e * U + u;
@@ -937,7 +940,7 @@ DEVFN void step_body(const KP &p)
     if (tid < WAVE) {
         for (int i = tid; i < S * 4 * NP; i += WAVE) {
             const int sl0 = i / (4 * NP), rem = i - sl0 * (4 * NP), k0 = rem / NP, j0 = rem - k0 * NP;
-            sh.rows[sl0][k0 * GRP + j0] = 0.0;
+            sh.rows[sl0][k0 * NP + j0] = 0.0;
         }
         for (int i = tid; i < S * NP; i += WAVE) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; sh.flg[sl0][j0] = 0; }
         if (tid < S * 8) (&sh.si[0][0])[tid] = st_si0;
@@ -2179,6 +2182,18 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     PUT(TB_ue_max_pkts(k) + f * U, lt[3].data(), n * U, int32_t);
     PUT(TB_ue_max_age(k) + f * U, lt[4].data(), n * U, int32_t);
     PUT(TB_lane_ue(k) + f * U, lt[5].data(), n * U, int32_t);
+    {   // set 1: lane = UE
+        const size_t set1 = (size_t)6 * (size_t)k.NSU;
+        std::vector<int32_t> ident(n * (size_t)U);
+        for (size_t i = 0; i < ident.size(); i++) ident[i] = (int32_t)(i % (size_t)U);
+        PUT(TB_ue_slice(k) + set1 + f * U, t->ue_slice, n * U, int32_t);
+        PUT(TB_ue_pos(k) + set1 + f * U, t->ue_pos, n * U, int32_t);
+        PUT(TB_ue_pkt_size(k) + set1 + f * U, t->ue_pkt_size, n * U, int32_t);
+        PUT(TB_ue_max_pkts(k) + set1 + f * U, t->ue_max_pkts, n * U, int32_t);
+        PUT(TB_ue_max_age(k) + set1 + f * U, t->ue_max_age, n * U, int32_t);
+        PUT(TB_lane_ue(k) + set1 + f * U, ident.data(), n * U, int32_t);
+        HIP_TRY(h, hipStreamSynchronize(stream));          // `ident` dies here
+    }
     PUT(TB_slot_ue(k) + f * NSL, sue.data(), n * NSL, int32_t);
     PUT(TB_slot_mp(k) + f * NSL, smp.data(), n * NSL, int32_t);
     PUT(TB_slot_pk(k) + f * NSL, spk.data(), n * NSL, int32_t);
@@ -2731,7 +2746,7 @@ int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     if (grid) *grid = h->cfg.batch;
     if (block) *block = h->nt;
-    if (lds_bytes) *lds_bytes = (int32_t)sizeof(SharedCore);
+    if (lds_bytes) *lds_bytes = (int32_t)(h->np == 8 ? sizeof(SharedCore<8>) : h->np == 10 ? sizeof(SharedCore<10>) : sizeof(SharedCore<16>));
     return RANENV_OK;
 }
 

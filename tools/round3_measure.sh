@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 step() {  # name timeout cmd...
   local name=$1 to=$2; shift 2
   timeout -k 10 $to "$@" > $out/$name.log 2>&1; local rc=$?
-  echo "[$name] rc=$rc"; tail -n ${TAILN:-2} $out/$name.log | cut -c1-600
+  echo "[$name] rc=$rc"; tail -n ${TAILN:-3} $out/$name.log | cut -c1-600
   if [ $rc -ne 0 ]; then echo "step $name failed: stopping"; exit 1; fi
 }
 if [ -z "$2" ]; then step pytest_gpu 900 python3 -m pytest tests -q -m gpu; fi
@@ -29,4 +29,14 @@ python3 tools/pmc_summary.py $out/pmc_stream_sq $out/pmc_stream_sq2 > $out/pmc_s
 python3 tools/pmc_summary.py $out/pmc_gather_sq $out/pmc_gather_sq2 > $out/pmc_gather_summary.txt
 step prof_stream 400 rocprofv3 --kernel-trace --stats -d $out/prof_stream -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --no-single-stream --no-gather
 step prof_gather 400 rocprofv3 --kernel-trace --stats -d $out/prof_gather -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --only-gather
+step bench_cfg1 300 python3 bench.py --config 1 --no-cpu-baseline
+step bench_cfg4 300 python3 bench.py --config 4 --no-cpu-baseline
+step bench_philox 300 python3 bench.py --traffic philox --no-cpu-baseline --no-gather
+if [ -f tools/variants/stamps.so ]; then
+  export RANENV_LIB=$PWD/tools/variants/stamps.so RANENV_LATE=0
+  for m in stream gather; do for c in 0 1; do
+    RANENV_SE_MODE=$m RANENV_COMPACT=$c step residency_${m}_compact$c 200 python3 tools/residency.py
+  done; done
+  unset RANENV_LIB RANENV_LATE
+fi
 echo "pass complete"
