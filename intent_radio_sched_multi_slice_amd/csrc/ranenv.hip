@@ -874,7 +874,7 @@ DEVFN void step_body(const KP &p)
     const bool compact = MODE == MODE_STEP && p.compact != 0;
     const int lane = tid < U ? tid : U - 1;
     const size_t tu = (size_t)sc * U + lane + (compact ? (size_t)0 : (size_t)6 * (size_t)p.NSU);
-    const int u = TB_lane_ue(p)[tu];
+    const int u = compact ? TB_lane_ue(p)[tu] : lane;      // (set 1 is the identity: no load, and the state loads need not wait for it)
     const int slc = TB_ue_slice(p)[tu], ue_pos = TB_ue_pos(p)[tu];
     const int pkt_size = TB_ue_pkt_size(p)[tu], max_pkts = TB_ue_max_pkts(p)[tu], max_age = TB_ue_max_age(p)[tu];
     const bool act = tid < U && !(compact && slc < 0);
@@ -1857,6 +1857,12 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     // sched_decisions (whole rows are needed) keep the streaming kernel
     bool gather = false;
     if constexpr (MODE != MODE_DENSE) gather = h->se_mode == RANENV_SE_GATHER && kp.se_tiles == nullptr;
+    // Compact steps pay off for the gather kernels throughout (-3...-7 %).  The streaming kernels want lane = UE: their row
+    // loads are coalesced in that order (a wave reads 256 contiguous bytes per RB; slice members first scatters its lanes
+    // over the whole 400-byte row), so they step compactly only where it was measured to win: under ranenv_rollout's
+    // overlapping partitions (-4 %; +15 % for two alternating ranges, +1.5 % for one launch per TTI).
+    if (!gather && kp.compact != 2) kp.compact = 0;
+    if (kp.compact) kp.compact = 1;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
         kp.se_mean_pool = h->d_se_mean; kp.se_rp = h->se_rp;
@@ -2506,6 +2512,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     finalize_kp(h, kp);
     rc = compact_for(h, kp, stream, &kp.compact);
     if (rc != RANENV_OK) return rc;
+    if (kp.compact) kp.compact = 2;                 // (2: the streaming kernels may step compactly too, see launch_range)
     // With auto-reset on, an env whose episode ends inside the rollout moves on to its next episode without the host:
     // the advance kernel + the step kernel in RESET mode follow that TTI's step on the partition's stream.  They are only
     // enqueued for TTIs at which some env of the partition finishes: the step counters are read once here and followed

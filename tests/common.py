@@ -45,3 +45,14 @@ def poisson_traffic_rows(tables: ScenarioTables, scen: int, rng: np.random.Gener
             ues = tables.slice_ues[scen, s, :n]
             out[t, ues] = rng.poisson(tables.slice_traffic[scen, s], n) * 1e6
     return out
+
+
+def comparable_views(wl):
+    """env.views() of a Workload, cloned, with the mean SE of UEs outside every slice blanked: nobody reads it, and a compact
+    step (include/ranenv.h) does not keep it up, so two envs stepped by different schedules may differ there and only there."""
+    import torch
+    env = wl.env
+    v = {k: x.clone() for k, x in env.views().items()}
+    in_slice = torch.as_tensor(wl.tables.ue_slice[wl.scenario] >= 0, device=env.device)
+    v["se_mean"] = torch.where(in_slice, v["se_mean"], torch.zeros_like(v["se_mean"]))
+    return v

@@ -6,6 +6,8 @@ import pytest
 
 torch = pytest.importorskip("torch")
 
+from tests.common import comparable_views
+
 pytestmark = pytest.mark.gpu
 
 OBS_TOL, REW_TOL = 1e-5, 1e-9
@@ -139,7 +141,7 @@ def test_rollout_and_partitions_equal_repeated_steps(policy, intra, parts):
             env.step()                                        # a joined step between two rollouts
             mid = env.views()["step_number"].clone()           # read on the caller's stream: ordered behind the partitions
             env.rollout(25)
-        v = {k: x.clone() for k, x in env.views().items()}
+        v = comparable_views(wl)
         outs.append((v, env.obs_inter.clone(), env.obs_intra.clone(), env.reward.clone(), env.done.clone(), mid))
         env.close()
     (va, oia, oaa, ra, da, _), (vb, oib, oab, rb, db, mid) = outs
@@ -212,7 +214,7 @@ def test_full_batch_episode_rollout_over_partitions_equals_single_stream_steps()
             for _ in range(4):
                 env.rollout(250)
         torch.cuda.synchronize()
-        finals.append(({k: x.clone() for k, x in env.views().items()}, env.obs_inter.clone(), env.obs_intra.clone(),
+        finals.append((comparable_views(wl), env.obs_inter.clone(), env.obs_intra.clone(),
                        env.reward.clone(), env.done.clone()))
         env.close()
     (va, oia, oaa, ra, da), (vb, oib, oab, rb, db) = finals

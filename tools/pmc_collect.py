@@ -19,7 +19,7 @@ def per_launch(dirs, counter):
         for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 kn = r["Kernel_Name"]
-                if r["Counter_Name"] == counter and re.search(r"ranenv_core_kernel\w*<0>", kn):
+                if r["Counter_Name"] == counter and re.search(r"ranenv_core_kernel\w*<0[,>]", kn):
                     vals.append(float(r["Counter_Value"]))
     vals = vals[2:] if len(vals) > 4 else vals
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
