@@ -347,6 +347,11 @@ int ranenv_set_autoreset(ranenv_handle h, int32_t enable, int32_t initial_episod
                          int32_t random_episodes, uint64_t seed, const int32_t *host_episode_no, void *stream);
 int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *dev_obs_inter, float *dev_obs_intra,
                      float *dev_term_obs_inter, float *dev_term_obs_intra, float *dev_term_obs_head, void *stream);
+/* The same for partition `part` only, enqueued on the partition's stream behind its last ranenv_step_part (stream plumbing as
+ * in ranenv_step_part; ranenv_wait_part then also covers the reset): a learner that steps ranges of the batch as in-order
+ * chains keeps the episode advance on the device and inside each chain.  All arrays are the whole-batch arrays. */
+int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done, float *dev_obs_inter, float *dev_obs_intra,
+                          float *dev_term_obs_inter, float *dev_term_obs_intra, float *dev_term_obs_head, void *stream);
 
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -394,19 +394,27 @@ class BatchedRanEnv:
         """Enqueue one TTI of range ``k`` on that range's stream, ordered behind what the caller's current stream holds
         now (the kernels that produced the scores).  The arguments are whole-batch tensors ([B, ...], already on the
         device: nothing is converted here); only range k's rows are read and written, and the caller must leave those
-        rows alone until ``step_wait(k)``.  Returns at once (one library call: ranenv_step_part)."""
+        rows alone until ``step_wait(k)``.  Returns at once (one library call: ranenv_step_part; with ``enable_autoreset``
+        a second one, ranenv_autoreset_part: finished envs of the range restart behind the step, ``done`` / ``reward`` keep
+        the terminal transition, ``term_obs_*`` the terminal observation)."""
         if self._ranges is None:
             raise RanEnvError("step_async needs set_ranges() first")
-        if self._recorder is not None or self._autoreset:
-            raise RanEnvError("step_async does not run the recorder / auto-reset hooks: use step()")
+        if self._recorder is not None:
+            raise RanEnvError("step_async does not run the history recorder: use step()")
         for name, x, dt in (("inter_scores", inter_scores, torch.float64), ("intra_choice", intra_choice, torch.uint8),
                             ("traffic_bits", traffic_bits, torch.float64), ("se_tiles", se_tiles, torch.float32)):
             if x is not None and not (x.dtype == dt and x.device == self.device and x.shape[0] == self.B and x.is_contiguous()):
                 raise RanEnvError(f"step_async: {name} must be a contiguous {dt} tensor [B, ...] on {self.device}")
+        cur = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         st = self._lib.ranenv_step_part(self._h, k, _ptr(inter_scores), _ptr(intra_choice), _ptr(traffic_bits), _ptr(se_tiles),
-                                        *self._p_out, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+                                        *self._p_out, cur)
         if st != 0:
             self._check(st, "ranenv_step_part")
+        if self._autoreset:       # the range's finished envs move on to their next episode behind the step, on the range's stream
+            st = self._lib.ranenv_autoreset_part(self._h, k, _ptr(self.done), _ptr(self.obs_inter), _ptr(self.obs_intra),
+                                                 _ptr(self.term_obs_inter), _ptr(self.term_obs_intra), _ptr(self.term_head_obs), cur)
+            if st != 0:
+                self._check(st, "ranenv_autoreset_part")
         # the inputs are read on the range's stream: they stay referenced here until the range's next launch (their
         # memory must not go back to the caching allocator meanwhile)
         self._keep[("async_inputs", k)] = (inter_scores, intra_choice, traffic_bits, se_tiles)

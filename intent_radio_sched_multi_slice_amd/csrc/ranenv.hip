@@ -2694,6 +2694,36 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     return RANENV_OK;
 }
 
+int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done, float *obs_inter, float *obs_intra,
+                          float *term_obs_inter, float *term_obs_intra, float *term_obs_head, void *stream_)
+{
+    if (!h || !dev_done) return fail(h, RANENV_E_INVALID, "null argument");
+    if (!h->ar_on) return fail(h, RANENV_E_STATE, "auto-reset is not configured (ranenv_set_autoreset)");
+    if (part < 0 || part >= h->n_parts || h->part_lo.empty()) return fail(h, RANENV_E_INVALID, "partition %d outside [0,%d) (ranenv_set_partitions)", part, h->n_parts);
+    int rc = check_ready(h, nullptr, nullptr, false);
+    if (rc != RANENV_OK) return rc;
+    if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_, ps = h->part_stream[(size_t)part];
+    if (stream != ps) {
+        HIP_TRY(h, hipEventRecord(h->part_in[(size_t)part], stream));
+        HIP_TRY(h, hipStreamWaitEvent(ps, h->part_in[(size_t)part], 0));
+    }
+    const int e0 = h->part_lo[(size_t)part], n = h->part_lo[(size_t)part + 1] - e0;
+    AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
+    a.e0 = e0;
+    hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, ps, a);
+    KP kp = h->kp;
+    kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
+    kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = nullptr; kp.done = nullptr;
+    kp.head_reward = nullptr; kp.compact = 0;
+    finalize_kp(h, kp);
+    const hipError_t e = launch_range<MODE_RESET>(h, kp, e0, n, ps);
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "auto-reset launch (partition %d): %s", part, hipGetErrorString(e));
+    HIP_TRY(h, hipEventRecord(h->part_done[(size_t)part], ps));
+    return RANENV_OK;
+}
+
 int ranenv_get_views(ranenv_handle h, ranenv_views *out)
 {
     if (!h || !out) return fail(h, RANENV_E_INVALID, "null argument");

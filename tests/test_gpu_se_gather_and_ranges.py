@@ -430,3 +430,38 @@ def test_compact_and_full_width_steps_agree_at_full_size(monkeypatch):
     assert torch.equal(a.env.obs_inter, b.env.obs_inter) and torch.equal(a.env.obs_intra, b.env.obs_intra)
     assert torch.equal(a.env.reward, b.env.reward)
     a.env.close(); b.env.close()
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_ranges_with_device_autoreset_equal_whole_batch_steps(se_mode):
+    """step_async / step_wait with enable_autoreset: every range restarts its finished envs behind its own step, on its own
+    stream (ranenv_autoreset_part).  Same numbers as env.step() with auto-reset (checked against the oracle elsewhere): state,
+    observations, terminal observations, rewards and done flags at every TTI, three episodes of 5 TTIs per env, the
+    scenario changing at every reset."""
+    _need_gpu()
+    envs = []
+    for _ in range(2):
+        env, tabs, se_pool, trf, start, dims = _short_episode_setup(16, 5, False, se_mode)
+        env.reset()
+        envs.append(env)
+    a, b = envs
+    ranges = b.set_ranges(2)
+    torch.cuda.synchronize()
+    for t in range(16):
+        oa, ra, da = a.step()
+        for k in range(2):
+            with torch.cuda.stream(b.range_stream(k)):
+                b.step_async(k)
+        for k, (lo, hi) in enumerate(ranges):
+            with torch.cuda.stream(b.range_stream(k)):
+                ob, rb, db = b.step_wait(k)
+                assert torch.equal(oa["obs_inter"][lo:hi], ob["obs_inter"]) and torch.equal(oa["obs_intra"][lo:hi], ob["obs_intra"]), (t, k)
+                assert torch.equal(ra[lo:hi], rb) and torch.equal(da[lo:hi], db), (t, k)
+                assert torch.equal(a.term_obs_inter[lo:hi], b.term_obs_inter[lo:hi]), (t, k)
+                for name, x in a.views().items():
+                    if x.shape[0] == a.B and name != "se_mean":
+                        assert torch.equal(x[lo:hi], b.views()[name][lo:hi]), (t, k, name)
+        if (t + 1) % 5 == 0:
+            assert bool(da.all())
+    assert a.views()["episode_number"].cpu().tolist() == b.views()["episode_number"].cpu().tolist()
+    a.close(); b.close()
