@@ -326,6 +326,9 @@ DEVFN RowPlan make_row_plan(int n)
 #ifndef RANENV_GATHER_STATE_FIRST
 #define RANENV_GATHER_STATE_FIRST 0
 #endif
+#ifndef RANENV_OBS_STAGE
+#define RANENV_OBS_STAGE 1
+#endif
 #ifndef RANENV_COLD_ARGS
 #define RANENV_COLD_ARGS 1
 #endif
@@ -594,6 +597,12 @@ struct SharedCore {
     int cnt[NP][NP + 4];          // RBs of each slot (padded like rows)
     unsigned char flg[NP][NP + 6];    // buffer-not-empty flag of each slot
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
+#if RANENV_OBS_STAGE
+    // this TTI's observation rows, staged here and written out by wave 0 as whole lines: written one float per lane and
+    // instruction they were ~170 partial-line store requests per env (profiles/r02_pmc_memsys.txt)
+    float ob_inter[NP * 10];
+    float ob_intra[NP * (2 * NP + 9)];
+#endif
 };
 
 // Workgroup barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its global loads and
@@ -1177,7 +1186,11 @@ DEVFN void step_body(const KP &p)
             srow(sh, slc, 3)[ue_pos] = se_mean_new;
             sh.cnt[slc][ue_pos] = rb_count;
             if (COLD(obs_intra) && ue_pos < Us) {                                          // per-UE entries (:186-200)
+#if RANENV_OBS_STAGE
+                float *oa = sh.ob_intra + slc * W;
+#else
                 float *oa = COLD(obs_intra) + ((size_t)e * S + slc) * W;
+#endif
                 oa[9 + ue_pos] = (float)occ_new;
                 oa[9 + Us + ue_pos] = (float)(se_mean_new / COLD(norm_se));
             }
@@ -1250,12 +1263,20 @@ DEVFN void step_body(const KP &p)
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
         const float tr = (float)(traffic_req / COLD(norm_traffic)), nu = (float)((double)n / COLD(norm_ues));
         if (COLD(obs_inter)) {                                                         // :160-173
+#if RANENV_OBS_STAGE
+            float *oi = sh.ob_inter + spos * 10;
+#else
             float *oi = COLD(obs_inter) + ((size_t)e * S + spos) * 10;
+#endif
             oi[0] = o0; oi[1] = o1; oi[2] = o2; oi[3] = a0; oi[4] = a1; oi[5] = a2;
             oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)(se_slice / COLD(norm_se));
         }
         if (COLD(obs_intra)) {
+#if RANENV_OBS_STAGE
+            float *oa = sh.ob_intra + s * W;
+#else
             float *oa = COLD(obs_intra) + ((size_t)e * S + s) * W;
+#endif
             oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
             oa[6] = (float)((double)rbs_s / (double)R); oa[7] = tr; oa[8] = nu;
             for (int k = n; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
@@ -1343,6 +1364,21 @@ DEVFN void step_body(const KP &p)
         if (COLD(done)) COLD(done)[e] = (MODE != MODE_RESET && step_new >= max_steps_e) ? 1 : 0;
     }
     } while (0);
+#if RANENV_OBS_STAGE
+    // wave 0 writes the staged observation rows out, a float per lane and whole lines per instruction (the per-UE entries were
+    // staged before the barrier in front of (3), the per-slice ones by this wave's first 16 lanes just now)
+    if (tid < WAVE && (COLD(obs_inter) || COLD(obs_intra))) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (COLD(obs_inter)) {
+            float *dst = COLD(obs_inter) + (size_t)e * S * 10;
+            for (int i = tid; i < S * 10; i += WAVE) dst[i] = sh.ob_inter[i];
+        }
+        if (COLD(obs_intra)) {
+            float *dst = COLD(obs_intra) + (size_t)e * S * W;
+            for (int i = tid; i < S * W; i += WAVE) dst[i] = sh.ob_intra[i];
+        }
+    }
+#endif
     RANENV_STAMP(7);
 
     // ---- (0') the next TTI's allocation, from the state this step leaves behind ----------------------
