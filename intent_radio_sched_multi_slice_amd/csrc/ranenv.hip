@@ -402,7 +402,9 @@ DEVFN void row_sums(SeStream<SE_NQ> &st, int R, InFn in, double &full, double &p
             // either x or 0), and cheaper than selecting a 64-bit addend
             const double d = (double)x[j];
             f[j] += d;
+#if RANENV_DIAG != 11      /* ablation 11: the full sum alone (what a stream costs without the masked half) */
             g[j] = fma(d, in(r0 + j) ? 1.0 : 0.0, g[j]);
+#endif
         }
         if (--left_in_leaf == 0) {
             fr = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
