@@ -1472,6 +1472,7 @@ struct SharedHead {
     double sv[GRP][3];            // slice drift means (-2: not declared)
     double thr_raw[GRP], occ_m[GRP];
     int nues[GRP];
+    double terms[3 * GRP], nw[3 * GRP];   // the reward's terms and weights (one lane fills them: LDS, not 784 B of scratch per lane)
 };
 
 // numpy pairwise_sum of n < 128 doubles by one lane
@@ -1614,7 +1615,7 @@ __global__ void __launch_bounds__(CORE_NT) ranenv_head_kernel(const KP p)
     __syncthreads();
     // ---- the rewards (one lane; a few dozen values) ------------------------------------------------
     if (tid == 0 && p.head_reward) {
-        double terms[3 * GRP], nw[3 * GRP];
+        double *terms = sh.terms, *nw = sh.nw;
         int q = 0;
         double r_col = 0.0;
         for (int sl = 0; sl < S; sl++) {
