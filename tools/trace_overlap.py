@@ -1,10 +1,10 @@
 """Timeline facts from a rocprofv3 --kernel-trace CSV: python tools/trace_overlap.py <kernel_trace.csv> [name filter]
 For the step kernel: launches, mean duration, mean gap between consecutive launches on the same queue, and the
 fraction of the span during which 0 / 1 / 2 / 3+ step kernels were running."""
-import csv, sys, collections
+import csv, sys, collections, re
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 flt = sys.argv[2] if len(sys.argv) > 2 else "ranenv_core_kernel"
-ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows if flt in r["Kernel_Name"] and "<0>" in r["Kernel_Name"]]
+ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows if flt in r["Kernel_Name"] and re.search(r"<0[,>]", r["Kernel_Name"])]
 ks.sort()
 ks = ks[len(ks) // 5:]          # drop the warm-up fifth
 dur = [e - s for s, e, _, _ in ks]
