@@ -1,0 +1,14 @@
+"""Rollout time per TTI for blocks of K TTIs between device syncs (the driver's K = 20 and the default 200):
+python tools/kprobe.py  -- RANENV_* knobs select the variant."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+wl, _ = make_bench_workload(2, torch.device("cuda", 0))
+env = wl.env
+env.set_partitions(3); env.reset(); env.rollout(30); torch.cuda.synchronize()
+for K in (20, 200):
+    ts = []
+    for _ in range(24 if K == 20 else 6):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); env.rollout(K); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f"K={K}: median {np.median(ts) / K * 1e6:.1f} us per TTI (min {min(ts) / K * 1e6:.1f})", flush=True)
