@@ -655,15 +655,22 @@ DEVFN void alloc_front(const KP &p, SharedCore<NP> &sh, int e, int hlen, bool ha
         if (ok1) { active = sh.si[s1][0]; nues1 = sh.si[s1][2]; bsize = sh.si[s1][3]; msg = sh.si[s1][5]; sorted = sh.si[s1][7]; }
         double score = -1.0;
         if (mapf) {
-            double occ_mb = 0.0, thr_mb = 0.0;
-            if (ok1 && active) {
-                const double pkt = (double)msg, bmax = (double)bsize;
-                occ_mb = ((np_sum_lds<NP>(srow(sh, s1, 0), nues1) / (double)nues1 * bmax) * pkt) / 1e6;   // mapf.py:63-74
-                asm volatile("" : "+v"(occ_mb));     // one row at a time: both rows in registers at once set the kernel's VGPR peak
-                thr_mb = ((np_sum_lds<NP>(srow(sh, s1, 1), nues1) / (double)nues1) * pkt) / 1e6;          // :75-90
+            // backlog and sent Mbit of every slice (mapf.py:63-90): the two rows side by side, lanes 0..15 the occupancy row and
+            // lanes 16..31 the window row of slice (lane & 15), instead of one after the other on 16 lanes
+            {
+                const int half = tid >> 4, sl2 = tid & (GRP - 1);
+                double v2 = 0.0;
+                if (tid < 2 * GRP && sl2 < S && sh.si[sl2][0] != 0) {
+                    const int n2 = sh.si[sl2][2];
+                    v2 = np_sum_lds<NP>(srow(sh, sl2, half), n2) / (double)n2;
+                    if (half == 0) v2 = v2 * (double)sh.si[sl2][3];                     // x buffer size
+                    v2 = (v2 * (double)sh.si[sl2][5]) / 1e6;                            // x message size, to Mbit
+                }
+                if (tid < 2 * GRP) xs[half][sl2] = v2;
             }
-            if (tid < GRP) { xs[0][s1] = occ_mb; xs[1][s1] = thr_mb; }
             wave_sync();
+            double occ_mb = 0.0, thr_mb = 0.0;
+            if (tid < GRP) { occ_mb = xs[0][s1]; thr_mb = xs[1][s1]; }
             double w = 0.0;
             if (tid < GRP) {
                 double mx = xs[0][0];
@@ -1203,7 +1210,6 @@ DEVFN void step_body(const KP &p)
         const double ws = wave_sum_f64((double)sent_u), wd = wave_sum_f64((double)drop_u);
         if ((tid & (WAVE - 1)) == 0) { acc_add(COLD(acc) + (size_t)e * 8 + 6, ws); acc_add(COLD(acc) + (size_t)e * 8 + 7, wd); }
     }
-    if (tid < GRP) { xr[0][tid] = 0.0; xr[1][tid] = 0.0; }
     RANENV_STAMP(5);
     wg_sync();
     RANENV_STAMP(6);
@@ -1223,10 +1229,26 @@ DEVFN void step_body(const KP &p)
         break;
     }
 #endif
-    if (tid >= GRP) break;                   // (3) is done by threads 0..15 (one wave)
+    if (tid >= WAVE) break;                  // (3) is done by wave 0
+    // The four means of every slice over its UEs -- the three drift rows and the SE row (common.py:343-378, ib_sched.py:146-157)
+    // -- one per lane (lane = 16 * row + sorted position) instead of four one after the other on 16 lanes: they are
+    // independent chains of LDS reads and additions, and this wave has nothing else to issue.
+    {
+        const int row4 = tid >> 4, sp4 = tid & (GRP - 1);
+        double mean4 = 0.0;
+        int s4 = 0, n4 = 0;
+        if (sp4 < S) { s4 = sh.si[sp4][7]; n4 = sh.si[s4][2]; }
+        const double sum4 = np_sum_lds<NP>(srow(sh, s4, row4), n4);
+        if (n4 > 0) mean4 = sum4 / (double)n4;
+        xr[row4][sp4] = mean4;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tid >= GRP) break;
 
     // ---- thread t < 16: slice at sorted position t (ib_sched.py:91) --------------------------------
     const int spos = tid;
+    const double mean_row[4] = {xr[0][tid], xr[1][tid], xr[2][tid], xr[3][tid]};
+    xr[0][tid] = 0.0; xr[1][tid] = 0.0;      // the reward's rows (filled by slice index below) start from zero
     const bool ok = spos < S;
     double sv[3] = {-2.0, -2.0, -2.0};
     int s = 0, active = 0;
@@ -1246,7 +1268,7 @@ DEVFN void step_body(const KP &p)
             for (int qi = 0; qi < 3; qi++) {
                 if (qi < npar) {
                     const int m = sh.pi[s][2 * qi];
-                    const double mean = np_sum_lds<NP>(srow(sh, s, m), n) / (double)n;
+                    const double mean = m == 0 ? mean_row[0] : (m == 1 ? mean_row[1] : mean_row[2]);
                     sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
                 }
             }
@@ -1260,7 +1282,7 @@ DEVFN void step_body(const KP &p)
             am[m] = undeclared ? 0.0 : 1.0;
             sv[m] = undeclared ? 0.0 : sv[m];
         }
-        const double se_slice = n > 0 ? np_sum_lds<NP>(srow(sh, s, 3), n) / (double)n : 0.0;   // :146-157
+        const double se_slice = n > 0 ? mean_row[3] : 0.0;                                      // :146-157
         const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
         const float tr = (float)(traffic_req / COLD(norm_traffic)), nu = (float)((double)n / COLD(norm_ues));
