@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--scenarios", type=int, default=200)
     ap.add_argument("--traces", type=int, default=50)
+    ap.add_argument("--se-mode", choices=("stream", "gather"), default="gather",
+                    help="how replayed SE tiles are read (gather: per-tile mean-SE sidecar + the allocated RBs only; same results)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     B, n_ep, T = args.batch, args.episodes, args.steps
@@ -37,6 +39,7 @@ def main():
         wl = make_mult_slice_workload(B, dev, policy=policy, intra=intra, n_scenarios=args.scenarios, n_traces=args.traces,
                                       trace_len=T, max_steps=T)
         env = wl.env
+        env.set_se_mode(args.se_mode)
         # episode number n: scenario n mod n_scenarios, channel trace n mod n_traces, traffic trace of its scenario
         first, count = 0, args.scenarios * 4
         ep = np.arange(first, first + count)
