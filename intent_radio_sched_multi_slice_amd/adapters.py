@@ -50,6 +50,9 @@ class _Dict:
     def __init__(self, spaces):
         self.spaces = dict(spaces)
 
+    def __getitem__(self, key):
+        return self.spaces[key]
+
 
 def _box(low, high, shape, dtype):
     if _spaces is not None:

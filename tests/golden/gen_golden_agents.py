@@ -102,6 +102,9 @@ def install_shims():
             super().__init__(spaces)
             self.spaces = dict(spaces)
 
+        def __getitem__(self, key):                          # gymnasium's Dict is subscriptable (agents/sched_twc.py:431)
+            return self.spaces[key]
+
     sp.Box, sp.Discrete, sp.Dict = Box, Discrete, Dict
     g.spaces = sp
     sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = g, sp
@@ -112,6 +115,29 @@ def install_shims():
         pl.f = None
         sys.modules["matplotlib"], sys.modules["matplotlib.pylab"] = mp, pl
     sys.path.insert(0, REF)
+
+
+def install_sb3_standins():
+    """agents/sched_twc.py and sched_colran.py import stable-baselines3 (absent here) for their trainers; the observation,
+    reward and action code needs none of it.  Attribute-holding stand-ins (PPO(...) just stores its arguments)."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            self.args, self.kwargs = a, k
+
+    sys.modules["gymnasium"].Env = object
+    sys.modules["gymnasium.spaces"].Space = object
+    mod("stable_baselines3"); mod("stable_baselines3.common")
+    mod("stable_baselines3.common.callbacks", CheckpointCallback=_Stub, BaseCallback=_Stub, EvalCallback=_Stub, EventCallback=_Stub)
+    mod("stable_baselines3.common.evaluation", evaluate_policy=None)
+    mod("stable_baselines3.common.vec_env", DummyVecEnv=_Stub, VecEnv=_Stub, sync_envs_normalization=None)
+    mod("stable_baselines3.ppo"); mod("stable_baselines3.ppo.ppo", PPO=_Stub)
+    mod("stable_baselines3.sac"); mod("stable_baselines3.sac.sac", SAC=_Stub)
 
 
 def describe_space(sp):
@@ -149,9 +175,16 @@ def main():
         def __init__(self, *a, **k):
             super().__init__(*a, generator_mode=True, **k)
 
+    install_sb3_standins()
+    from agents import sched_twc as ref_twc, sched_colran as ref_col
+    from agents.sched_colran import SchedColORAN
+    from agents.sched_twc import SchedTWC
+    ref_twc.np = _StableNumpy(); ref_col.np = _StableNumpy()
+
     steps, seed = 50, 10
     out = {"cfg": np.array([5, 25, 135, 5, 5, seed, steps])}
-    for agent_name, AgentCls in (("ib_sched", IBSched), ("marr", MARR), ("mapf", MAPF)):
+    for agent_name, AgentCls in (("ib_sched", IBSched), ("marr", MARR), ("mapf", MAPF), ("sched_twc", SchedTWC),
+                                 ("sched_colran", SchedColORAN)):
         env_config = {"seed": seed, "agent": agent_name, "root_path": "/nonexistent", "scenario": "mult_slice", "save_hist": False,
                       "enable_random_episodes": False}
         cfg = dict(comm_env.DEFAULT_CONFIGS["mult_slice"], max_number_steps=steps)
@@ -161,8 +194,15 @@ def main():
                                    max_episode_number=2, enable_random_episodes=env_config["enable_random_episodes"], config=cfg,
                                    max_ues_slice=5)
         ce = env.comm_env
-        agent = AgentCls(env, ce.max_number_ues, ce.max_number_slices, ce.max_number_basestations, ce.num_available_rbs,
-                         seed=env_config["seed"])
+        head = agent_name.startswith("sched_")
+        if head:        # env_creator's "rl" branch (simu.py:380-397): keyword arguments, no evaluation env
+            agent = AgentCls(env=env, max_number_ues=ce.max_number_ues, max_number_slices=ce.max_number_slices,
+                             max_number_basestations=ce.max_number_basestations, num_available_rbs=ce.num_available_rbs,
+                             eval_env=None, agent_name=agent_name, seed=env_config["seed"], episode_evaluation_freq=None,
+                             number_evaluation_episodes=None, checkpoint_episode_freq=10, eval_initial_env_episode=None)
+        else:
+            agent = AgentCls(env, ce.max_number_ues, ce.max_number_slices, ce.max_number_basestations, ce.num_available_rbs,
+                             seed=env_config["seed"])
         env.set_agent_functions(agent.obs_space_format, agent.action_format, agent.calculate_reward,
                                 agent.get_obs_space(), agent.get_action_space())
         agent.init_agent()
@@ -192,6 +232,9 @@ def main():
                 action = {"player_0": rng.uniform(-1, 1, S)}
                 action.update({f"player_{s + 1}": int(rng.integers(0, 3)) for s in range(S)})
                 flat_a = np.concatenate([action["player_0"], [action[f"player_{s + 1}"] for s in range(S)]])
+            elif head:                                       # the SB3 model's output: Box(-1, 1, (S,)) (its PPO is a stand-in here)
+                action = rng.uniform(-1, 1, S)
+                flat_a = action.copy()
             else:
                 action = agent.step(obs)                     # simu.py:555-558
                 flat_a = np.asarray(action, dtype=float)

@@ -129,3 +129,44 @@ def test_batched_marl_view_carries_the_reference_spaces():
         assert tuple(obs[p]["observations"].shape[1:]) == tuple(sp.spaces["observations"].shape)
         assert tuple(obs[p]["action_mask"].shape[1:]) == tuple(sp.spaces["action_mask"].shape)
     wl.env.close()
+
+
+@pytest.mark.parametrize("name,col", [("sched_twc", 0), ("sched_colran", 1)])
+def test_fixture_of_the_real_head_agents_replays_on_the_gpu_facade(name, col, tmp_path):
+    """The reference's real SchedTWC / SchedColORAN classes (agents/sched_twc.py, agents/sched_colran.py: their own
+    observation of 10 values per slice and their own rewards, IBSched's action_format with round-robin inside the slices)
+    ran on the facade when the fixture was made.  Replayed here: the fixture's actions through the GPU facade with this build's
+    plugins, the head kernel (ranenv_bind_head_outputs) producing the observation and both rewards every TTI."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd import plugins
+    from intent_radio_sched_multi_slice_amd.comm_env import DEFAULT_CONFIGS, MARLCommEnv
+    from intent_radio_sched_multi_slice_amd.scenario import slice_usecase_from_req
+    fx = load_golden("agents_on_facade")
+    S, U, R, G, Us, seed, steps = (int(x) for x in fx["cfg"])
+    cfg = dict(DEFAULT_CONFIGS["mult_slice"], max_number_steps=steps)
+    env = MARLCommEnv(plugins.MimicQuadriga, plugins.MultSliceTraffic, plugins.SimpleMobility, plugins.MultSliceAssociation,
+                      "mult_slice", name, seed, root_path=str(tmp_path), config=cfg, max_episode_number=2, max_ues_slice=Us)
+    ce = env.comm_env
+    agent = _Agent(env, ce.max_number_ues, ce.max_number_slices, ce.max_number_basestations, ce.num_available_rbs,
+                   max_ues_slice=Us, rbs_per_rbg=G, sort=False)       # their IBSched is built with enable_sort_slices=False
+    env.set_agent_functions(agent.obs_space_format, agent.action_format, agent.calculate_reward, None, None)
+    dev = env._dev
+    dev.enable_heads(None)                   # outputs bound before the reset: the reset observation is a head observation too
+    env.reset(seed=seed, options={"initial_episode": 0})
+    dev.set_slice_usecase(slice_usecase_from_req(ce.slice_req, S)[None])      # SchedColORAN's slice-name table as data
+    np.testing.assert_allclose(dev.head_obs[0].cpu().numpy(), fx[f"{name}_reset_obs"], rtol=2e-6, atol=OBS_TOL)
+    for t in range(steps):
+        a = fx[f"{name}_action"][t]
+        action = {"player_0": a.copy()}
+        action.update({f"player_{s + 1}": 0 for s in range(S)})                # fixed_intra = "rr" (sched_twc.py:415-422)
+        env.step(action)
+        raw = env._last_raw
+        sched = np.asarray(raw["sched_decision"])[0]
+        assert np.array_equal(sched.sum(axis=1).astype(np.int32), fx[f"{name}_rb_count"][t]), (name, t)
+        assert np.array_equal(env._last_traffic, fx[f"{name}_traffic"][t]), (name, t)
+        for k in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts", "buffer_occupancies", "buffer_latencies"):
+            assert np.array_equal(raw[k], fx[f"{name}_{k}"][t]), (name, t, k)
+        np.testing.assert_allclose(dev.head_obs[0].cpu().numpy(), fx[f"{name}_obs"][t], rtol=2e-6, atol=OBS_TOL, err_msg=str((name, t)))
+        np.testing.assert_allclose(dev.head_reward[0, col].item(), fx[f"{name}_reward"][t, 0], rtol=0, atol=REW_TOL, err_msg=str((name, t)))
+    env.close()
