@@ -168,3 +168,16 @@ def test_what_separates_the_per_file_metrics_from_the_live_ones():
     # the UEs whose buffer was empty before as over-fulfilled: never more violations, never a larger distance
     assert (C2[:, 0, 0] <= A2[:, 0, 0]).all() and (C2[:, 0, 2] >= A2[:, 0, 2] - 1e-12).all()
     assert A.shape == (3, 60, 4) and (A[:, :, 0] > 0).sum() > 100 and (A[:, :, 0] < A[:, :, 0].max()).sum() > 20
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/results"), reason="the reference is mounted in the build container only")
+def test_reference_result_scripts_read_this_builds_history_files():
+    """tests/golden/check_reference_readers.py in a subprocess (it puts the reference's packages and stand-ins into
+    sys.modules): the real MARR and MAPF play the same episodes on the facade with save_hist; the reference's own
+    fair_comparison_check (results/gen_results.py:1587-1635) then finds the exogenous inputs identical across the agents' files,
+    and its violation / distance / throughput functions read every file."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(GOLDEN, "check_reference_readers.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "fair_comparison_check passed" in out.stdout
