@@ -170,3 +170,83 @@ def test_fixture_of_the_real_head_agents_replays_on_the_gpu_facade(name, col, tm
         np.testing.assert_allclose(dev.head_obs[0].cpu().numpy(), fx[f"{name}_obs"][t], rtol=2e-6, atol=OBS_TOL, err_msg=str((name, t)))
         np.testing.assert_allclose(dev.head_reward[0, col].item(), fx[f"{name}_reward"][t, 0], rtol=0, atol=REW_TOL, err_msg=str((name, t)))
     env.close()
+
+
+def _exogenous_inputs_of_the_fixture(fx, name):
+    """The episode's scenario, SE tiles and traffic as the facade's plugins drew them from the env's one rng (reset:
+    association, mobility, channel; every TTI: mobility, channel, traffic), regenerated with this build's plugins and checked
+    against what the fixture recorded."""
+    from intent_radio_sched_multi_slice_amd import plugins
+    from intent_radio_sched_multi_slice_amd.scenario import IDLE_UE_MAX_AGE, IDLE_UE_MAX_PKTS, IDLE_UE_PKT_SIZE, ScenarioTables
+    S, U, R, G, Us, seed, steps = (int(x) for x in fx["cfg"])
+    rng = np.random.default_rng(seed)
+    ues = plugins.UEs(U, np.repeat(IDLE_UE_MAX_AGE, U), np.repeat(IDLE_UE_MAX_PKTS, U), np.repeat(IDLE_UE_PKT_SIZE, U))
+    mob = plugins.SimpleMobility(U, rng, "")
+    ch = plugins.MimicQuadriga(U, 1, np.array([R]), rng, "", "mult_slice")
+    tr = plugins.MultSliceTraffic(U, rng, "")
+    assoc = plugins.MultSliceAssociation(ues, U, 1, S, rng, "")
+    bua, bsa, sua, req = assoc.step(np.zeros((1, U)), np.zeros((1, S)), np.zeros((S, U)), {f"slice_{i}": {} for i in range(S)}, 0, 0)
+    assert np.array_equal(sua, fx[f"{name}_slice_ue_assoc"])
+    se = [np.asarray(ch.step(0, 0, mob.step(0, 0)))[0]]
+    traffic = []
+    for t in range(steps):
+        m = mob.step(t, 0)
+        se.append(np.asarray(ch.step(t, 0, m))[0])
+        traffic.append(np.asarray(tr.step(sua, req, t, 0)))
+        np.testing.assert_array_equal(se[-1].sum(axis=1), fx[f"{name}_se_sum"][t])
+        np.testing.assert_array_equal(traffic[-1], fx[f"{name}_traffic"][t])
+    return bua, bsa, sua, req, ues, np.stack(se).astype(np.float32), np.stack(traffic)
+
+
+@pytest.mark.parametrize("name", ["ib_sched", "marr", "mapf"])
+def test_fused_step_kernel_against_the_real_agents_episode(name):
+    """The same fixture through the BATCHED path: the fused step kernel does action_format, UEs.step, obs_space_format and
+    calculate_reward itself.  For the real IBSched's episode it gets the fixture's scores and per-slice scheduler choices; for
+    the real MARR's / MAPF's it gets nothing -- the device policy must produce the very scores the reference's agent.step
+    returned, TTI after TTI, in closed loop.  RB ranges, packets and occupancies exact, observations 1e-5, rewards 1e-9."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables
+    fx = load_golden("agents_on_facade")
+    S, U, R, G, Us, seed, steps = (int(x) for x in fx["cfg"])
+    bua, bsa, sua, req, ues, se, traffic = _exogenous_inputs_of_the_fixture(fx, name)
+    marl = name == "ib_sched"
+    tabs = ScenarioTables.empty(1, S, U, Us)
+    tabs.set_from_reference(0, bsa, sua, req, marl, (ues.pkt_sizes, ues.max_buffer_pkts, ues.max_buffer_latencies))
+    B = 3
+    env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us, n_scenarios=1, max_steps=steps)
+    env.load_scenarios(tabs)
+    env.set_episodes(scenario=0)
+    env.set_policy({"ib_sched": 0, "marr": 1, "mapf": 2}[name], {"ib_sched": 255, "marr": 0, "mapf": 1}[name])
+    tile = lambda t: np.broadcast_to(np.ascontiguousarray(se[t].T), (B, R, U))
+    obs = env.reset(se_tiles=tile(0))
+
+    def flat(o, b):
+        oi, oa = o["obs_inter"][b].cpu().numpy(), o["obs_intra"][b].cpu().numpy()
+        return np.concatenate([oi, oa.ravel()]) if marl else oi
+    np.testing.assert_allclose(flat(obs, 1), fx[f"{name}_reset_obs"], rtol=0, atol=OBS_TOL)
+    for t in range(steps):
+        a = fx[f"{name}_action"][t]
+        tb = np.broadcast_to(traffic[t], (B, U))
+        if marl:
+            sc = np.broadcast_to(a[:S], (B, S))
+            ic = np.broadcast_to(a[S:].astype(np.uint8), (B, S))
+            obs, rew, done = env.step(sc, ic, tb, tile(t + 1))
+        else:
+            obs, rew, done = env.step(None, None, tb, tile(t + 1))
+            # the device's MARR / MAPF against the real agent.step(obs) of this TTI
+            np.testing.assert_allclose(env.views()["policy_scores"][2].cpu().numpy(), a, rtol=0, atol=1e-12, err_msg=str((name, t)))
+        v = {k: x[1].cpu().numpy() for k, x in env.views().items()}
+        ro = {k: x[1].cpu().numpy() for k, x in env.raw_observation().items()}
+        cnt = fx[f"{name}_rb_count"][t]
+        assert np.array_equal(v["rb_count"], cnt), (name, t)
+        assert np.array_equal(v["rb_start"][cnt > 0], fx[f"{name}_rb_start"][t][cnt > 0]), (name, t)
+        for k in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts", "buffer_occupancies", "buffer_latencies"):
+            assert np.array_equal(ro[k], fx[f"{name}_{k}"][t]), (name, t, k)
+        np.testing.assert_allclose(flat(obs, 0), fx[f"{name}_obs"][t], rtol=0, atol=OBS_TOL, err_msg=str((name, t)))
+        want = fx[f"{name}_reward"][t]
+        got = rew[2].cpu().numpy() if marl else rew[2, :1].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=REW_TOL, err_msg=str((name, t)))
+    assert bool(done.all())
+    env.close()
