@@ -250,3 +250,38 @@ def test_fused_step_kernel_against_the_real_agents_episode(name):
         np.testing.assert_allclose(got, want, rtol=0, atol=REW_TOL, err_msg=str((name, t)))
     assert bool(done.all())
     env.close()
+
+
+@pytest.mark.parametrize("name,reward", [("sched_twc", "twc"), ("sched_colran", "colran")])
+def test_head_vec_env_against_the_real_head_agents_episode(name, reward):
+    """adapters.HeadVecEnv (the SB3 VecEnv view: head kernel + IBSched's action_format with round-robin on the device, SE and
+    traffic replayed from HBM pools) on the episode the real SchedTWC / SchedColORAN played: their observation and reward
+    at every TTI."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.adapters import HeadVecEnv
+    from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
+    from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables, slice_usecase_from_req
+    fx = load_golden("agents_on_facade")
+    S, U, R, G, Us, seed, steps = (int(x) for x in fx["cfg"])
+    bua, bsa, sua, req, ues, se, traffic = _exogenous_inputs_of_the_fixture(fx, name)
+    tabs = ScenarioTables.empty(1, S, U, Us)
+    tabs.set_from_reference(0, bsa, sua, req, False, (ues.pkt_sizes, ues.max_buffer_pkts, ues.max_buffer_latencies))
+    B = 2
+    env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us, n_scenarios=1, max_steps=steps)
+    env.load_scenarios(tabs)
+    env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se[1:], 1, 2)), device=env.device))    # the steps' tiles
+    env.bind_traffic_pool(torch.as_tensor(traffic.astype(np.int32), device=env.device))
+    env.set_episodes(scenario=0, se_base=0, se_len=steps, trf_base=0, trf_len=steps)
+    venv = HeadVecEnv(env, reward=reward, slice_usecase=slice_usecase_from_req(req, S)[None])
+    env.reset(se_tiles=np.broadcast_to(np.ascontiguousarray(se[0].T), (B, R, U)))          # the reset's own channel draw
+    np.testing.assert_allclose(env.head_obs[1].cpu().numpy(), fx[f"{name}_reset_obs"], rtol=2e-6, atol=OBS_TOL)
+    for t in range(steps):
+        obs, rew, dones, infos = venv.step(np.broadcast_to(fx[f"{name}_action"][t], (B, S)))
+        if t < steps - 1:          # (at the terminal TTI the VecEnv protocol hands back the next episode's first observation)
+            np.testing.assert_allclose(obs[0], fx[f"{name}_obs"][t], rtol=2e-6, atol=OBS_TOL, err_msg=str((name, t)))
+        else:
+            np.testing.assert_allclose(infos[0]["terminal_observation"], fx[f"{name}_obs"][t], rtol=2e-6, atol=OBS_TOL)
+        np.testing.assert_allclose(rew[1], fx[f"{name}_reward"][t, 0], rtol=2e-6, atol=1e-6, err_msg=str((name, t)))
+        assert bool(dones[0]) == (t == steps - 1)
+    venv.close()
