@@ -317,6 +317,9 @@ DEVFN RowPlan make_row_plan(int n)
 #ifndef RANENV_SE_DEPTH
 #define RANENV_SE_DEPTH 1
 #endif
+#ifndef RANENV_SE_RING
+#define RANENV_SE_RING 0           /* > 0: the lean streaming kernel keeps its SE queue in LDS, this many 8-row groups per wave */
+#endif
 #ifndef RANENV_DEFER_STATE
 #define RANENV_DEFER_STATE 2   /* the part of the UE state the allocation does not need is requested 0: at kernel entry, 1: before
                                   the queue's last turn, 2: after the stream (default: ~20 registers fewer while the tile
@@ -368,7 +371,78 @@ struct SeStream {
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
+    // the queue as row_sums sees it: slot d's eight values (`after` = groups requested behind it: unused here, the
+    // compiler counts its own loads), and the request that refills the slot
+    static constexpr int NSLOT = SE_NQ;
+    DEVFN void take(int d, float (&x)[8], int) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = q[d][j];
+    }
+    DEVFN void refill(int d, int r0) { load(q[d], r0); }
 };
+
+// The same queue in LDS instead of registers (-DRANENV_SE_RING=<groups>): every wave owns NG x 8 rows of 64 floats in the
+// workgroup's dynamic LDS and requests its rows with buffer_load ... lds (the data goes from the memory pipeline straight
+// into LDS, no VGPR holds it while in flight), so the depth of the queue costs LDS, not the registers that set the
+// occupancy.  The compiler knows nothing of these loads: the waits are written here.  vmcnt counts every vector memory
+// operation of the wave and loads retire in order, so "at most 8 x after outstanding" means slot d's eight rows have
+// landed whatever else the compiler has in flight (its own operations can only make the wait longer).
+extern __shared__ __attribute__((aligned(16))) float ranenv_dyn_lds[];
+template <int NG>
+struct SeRing {
+    typedef int rsrc4 __attribute__((ext_vector_type(4)));
+    rsrc4 rsrc;
+    int voff, row_bytes, last_row;
+    unsigned m0_base;              // LDS byte offset of this wave's ring (wave-uniform)
+    const float *rd;               // this lane's column of the ring
+    static constexpr int NSLOT = NG;
+    DEVFN void refill(int d, int r0)
+    {
+        int soff = r0 * row_bytes;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's previous rows were read out
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int so = soff < last_row ? soff : last_row;
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                         :: "s"(m0_base + (unsigned)((d * 8 + j) * 256)), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+            soff += row_bytes;
+        }
+    }
+    DEVFN void take(int d, float (&x)[8], int after)
+    {
+        if (after <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (after == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (after == 4) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (after == 5) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = rd[(d * 8 + j) * 64];
+    }
+    DEVFN void init(const float *tile, int U, int u, int R)
+    {
+        static_assert(NG >= 1 && NG <= 7, "vmcnt is a 6-bit counter");
+        // the descriptor's four words by hand (what __builtin_amdgcn_make_buffer_rsrc packs: base, stride 0, bytes, flags)
+        const unsigned long long a = (unsigned long long)tile;
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+        rsrc.z = __builtin_amdgcn_readfirstlane(U * R * 4);
+        rsrc.w = 0x00020000;
+        voff = u * 4; row_bytes = U * 4; last_row = (R - 1) * U * 4;
+        const int wave = threadIdx.x >> 6;
+        typedef __attribute__((address_space(3))) float *lds_ptr_t;
+        const unsigned base = (unsigned)(size_t)(lds_ptr_t)ranenv_dyn_lds;
+        m0_base = __builtin_amdgcn_readfirstlane(base + (unsigned)(wave * NG * 8 * 256));
+        rd = ranenv_dyn_lds + wave * NG * 8 * 64 + (threadIdx.x & 63);
+#pragma unroll
+        for (int d = 0; d < NG; d++) if (d * 8 < R) refill(d, d * 8);
+    }
+};
+template <int NQ> struct SeSource { typedef SeStream<NQ> type; };
+#define SE_RING_CASE(n) template <> struct SeSource<-n> { typedef SeRing<n> type; };
+SE_RING_CASE(1) SE_RING_CASE(2) SE_RING_CASE(3) SE_RING_CASE(4) SE_RING_CASE(5) SE_RING_CASE(6)
+#undef SE_RING_CASE
 
 // Sums of one row: `full` over all R RBs, `part` over the RBs selected by in(r).
 // Accumulators start at 0.0 instead of being initialised with the leaf's first group: 0.0 + x == x
@@ -378,11 +452,13 @@ struct SeStream {
 // `after_issue` runs once, before the last turn of the queue (no load is requested in that turn): what the caller
 // loads there completes behind the tile (loads retire in order) while the last groups are being summed, and needs
 // no register during the rest of the stream.
-template <int SE_NQ, typename InFn, typename Hook>
-DEVFN void row_sums(SeStream<SE_NQ> &st, int R, InFn in, double &full, double &part, Hook after_issue)
+template <typename Src, typename InFn, typename Hook>
+DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook after_issue)
 {
+    constexpr int SE_NQ = Src::NSLOT;
     const RowPlan pl = make_row_plan(R);
     const int tail = R & 7, G = R >> 3;
+    const int GT = G + (tail > 0 ? 1 : 0);                   // groups requested in all (the partial one included)
     double f[8], g[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { f[j] = 0.0; g[j] = 0.0; }
@@ -433,8 +509,11 @@ DEVFN void row_sums(SeStream<SE_NQ> &st, int R, InFn in, double &full, double &p
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) {
             if (gi + d < G) {
-                consume(st.q[d], (gi + d) * 8);
-                if ((gi + d + SE_NQ) * 8 < R) st.load(st.q[d], (gi + d + SE_NQ) * 8);
+                float x[8];
+                const int behind = GT - 1 - (gi + d);
+                st.take(d, x, behind < SE_NQ - 1 ? behind : SE_NQ - 1);
+                consume(x, (gi + d) * 8);
+                if ((gi + d + SE_NQ) * 8 < R) st.refill(d, (gi + d + SE_NQ) * 8);
             }
         }
     };
@@ -446,7 +525,7 @@ DEVFN void row_sums(SeStream<SE_NQ> &st, int R, InFn in, double &full, double &p
     if (tail > 0) {
         const int m = G % SE_NQ;
 #pragma unroll
-        for (int d = 0; d < SE_NQ; d++) if (m == d) add_tail(st.q[d], G * 8);
+        for (int d = 0; d < SE_NQ; d++) if (m == d) { float x[8]; st.take(d, x, 0); add_tail(x, G * 8); }
     }
     if (pl.n_leaves == 1) { full = lf; part = lg; return; }
     full = lf + rf; part = lg + rg;
@@ -951,7 +1030,7 @@ DEVFN void step_body(const KP &p)
     }
     const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
-    SeStream<GATHER ? 1 : NQ> se1;
+    typename SeSource<GATHER ? 1 : NQ>::type se1;
     if (!GATHER) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables
@@ -992,7 +1071,7 @@ DEVFN void step_body(const KP &p)
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1 || RANENV_DIAG == 10
-        my_full = (double)se1.q[0][0] + (double)us1; my_part = (double)uc1;
+        { float x0[8]; se1.take(0, x0, 0); my_full = (double)x0[0] + (double)us1; my_part = (double)uc1; }
 #elif RANENV_DIAG == 2
         row_sums(se1, R, [=](int r) { return false; }, my_full, my_part, hook); my_part = (double)(us1 + uc1);
 #else
@@ -1436,7 +1515,10 @@ DEVFN void step_body(const KP &p)
 #define RANENV_CORE_ATTR
 #endif
 template <int MODE, int NP>
-__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p) { step_body<MODE, RANENV_SE_DEPTH, false, NP>(p); }
+__global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
+{
+    step_body<MODE, RANENV_SE_RING ? -RANENV_SE_RING : RANENV_SE_DEPTH, false, NP>(p);
+}
 template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
 {
@@ -1894,6 +1976,7 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
 template <int MODE, int NP>
 void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
 {
+    const unsigned ring_bytes = (unsigned)(RANENV_SE_RING * 8 * 256) * ((block.x + 63u) / 64u);     // the SE queue in LDS, per wave
     if (gather) {
         if constexpr (MODE != MODE_DENSE) {
             if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
@@ -1901,10 +1984,10 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
         }
     } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
         if (h->small_batch) hipExtLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
-        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, ring_bytes, stream, ev0, ev1, 0, kp);
     } else {
         if (h->small_batch) hipLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, kp);
-        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, kp);
+        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, ring_bytes, stream, kp);
     }
 }
 
