@@ -126,7 +126,7 @@ def block_stats(times, env_steps_per_block: float, steps: int):
             "value_min": env_steps_per_block / max(times), "value_max": env_steps_per_block / min(times)}
 
 
-def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, launch_ms, n_launches, parts, pmc, metrics,
+def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, kms, parts, pmc, metrics,
                workload_extra="", extras=None):
     """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region (the median block: the
     whole TTI of the whole batch); the step kernel's per-launch duration (the dispatch's own timestamps, from the same
@@ -136,11 +136,14 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
     ms_per_step = st["ms_per_step"]
     alg_bytes = alg_bytes_env_step * batch                       # per TTI of one rank's batch
     achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9            # per-GPU GB/s on the wall clock
-    launch_bytes = alg_bytes / parts
+    launch_ms, n_launches = kms["step"], kms["n_launches"]
+    ttis_per_launch = kms.get("n_ttis", n_launches) / max(1, n_launches)      # inside a rollout a launch covers several TTIs
+    launch_bytes = alg_bytes / parts * ttis_per_launch
     launch_gbs = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic = (pmc or {}).get("stream")
     schedule = (f"ranenv_rollout: the K TTIs of the device policy enqueued in one call, batch stepped as {parts} partitions on "
-                f"{parts} HIP streams (one launch of the step kernel per partition and TTI), no host between TTIs") if parts > 1 else \
+                f"{parts} HIP streams, no host between TTIs; a launch of the step kernel takes its partition through "
+                f"{ttis_per_launch:.3g} TTIs on average (up to K/4, at most 10)") if parts > 1 else \
         "one launch of the step kernel per TTI on one stream"
     line = {
         "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling"
@@ -162,11 +165,12 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
                      "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
                      "traffic_source": (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, one launch per "
                                         f"TTI on one stream, {traffic.get('date', 'undated')}; not measured in this run)") if traffic else None,
-                     "kernel": "ranenv_core_kernel<STEP> (one TTI = %d concurrent launch(es) of it)" % parts,
+                     "kernel": "ranenv_core_kernel<STEP> (%d concurrent launch(es) of it, %.3g TTIs per launch)" % (parts, ttis_per_launch),
                      "algorithmic_bytes_per_env_step": alg_bytes_env_step,
                      "algorithmic_bytes_per_tti": alg_bytes,
                      "dominant_kernel": {"name": "ranenv_core_kernel<STEP>", "ms": launch_ms, "n_launches": n_launches,
-                                         "envs_per_launch": batch / parts, "algorithmic_bytes": launch_bytes,
+                                         "envs_per_launch": batch / parts, "ttis_per_launch": ttis_per_launch,
+                                         "algorithmic_bytes": launch_bytes,
                                          "achieved": launch_gbs, "frac": launch_gbs / HBM_PEAK_GBS,
                                          "concurrent_launches": parts,
                                          "source": "hipExtLaunchKernel start/stop events of every launch, the K steps repeated "
@@ -177,7 +181,7 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
     return line
 
 
-def gather_block(env, batch, world, steps, times, launch_ms, n_launches, parts, pmc):
+def gather_block(env, batch, world, steps, times, kms, parts, pmc):
     """The `se_gather` object: the headline schedule in the SE gather mode, against the gather mode's own bytes and --
     it is not HBM-bound -- against the VALU issue rate."""
     st = block_stats(times, batch * world * steps, steps)
@@ -188,7 +192,8 @@ def gather_block(env, batch, world, steps, times, launch_ms, n_launches, parts, 
     out.update({"bytes_per_env_step": b_env,
                 "bytes_model": "4*R (allocated RBs, each read once) + 8*U (sidecar row of per-UE mean SE) + 180*U + S*(85+8*Us) + 4",
                 "hbm_frac": hbm_frac, "kernel": "ranenv_core_kernel_gather<STEP>",
-                "dominant_kernel_ms": launch_ms, "n_launches": n_launches, "concurrent_launches": parts})
+                "dominant_kernel_ms": kms["step"], "n_launches": kms["n_launches"],
+                "ttis_per_launch": kms.get("n_ttis", kms["n_launches"]) / max(1, kms["n_launches"]), "concurrent_launches": parts})
     g = (pmc or {}).get("gather")
     if g and g.get("valu_insts_per_launch"):
         issue_s = g["valu_insts_per_launch"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ)
@@ -381,7 +386,7 @@ def main():
         else:
             tg, kg = rollout_variant()
             if rank == 0:
-                extras["se_gather"] = gather_block(env, batch, world, K, tg, kg["step"], kg["n_launches"], parts, pmc)
+                extras["se_gather"] = gather_block(env, batch, world, K, tg, kg, parts, pmc)
             if args.only_gather:
                 times, kms = tg, kg
                 gathered = gm(local_metrics(env.reward, env.views(), env.done, K))
@@ -390,7 +395,7 @@ def main():
     if rank == 0:
         line = build_line(args, world, batch, label, (env.S, env.U, env.R),
                           env.algorithmic_bytes_per_env_step("gather" if args.only_gather else "stream"),
-                          times, kms["step"], kms["n_launches"], parts, pmc, summarize(gathered.cpu()),
+                          times, kms, parts, pmc, summarize(gathered.cpu()),
                           workload_extra=(", Poisson traffic pool" if args.traffic == "pool"
                                           else ", Poisson traffic drawn on the device (Philox4x32-10)"),
                           extras=extras)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 6
+#define RANENV_ABI_VERSION 7
 
 enum {
     RANENV_OK = 0,
@@ -276,6 +276,9 @@ int ranenv_get_se_sidecars(ranenv_handle h, double **dev_row_mean, float **dev_u
  * partitions: one launch per partition and TTI). */
 int ranenv_profile_begin(ranenv_handle h);
 int ranenv_profile_end(ranenv_handle h, double *avg_ms, int32_t *n_launches);
+/* TTIs covered by the launches timed since ranenv_profile_begin: inside ranenv_rollout one launch may take its envs
+ * through several TTIs (see there), so n_ttis / n_launches TTIs went into the average launch. */
+int ranenv_profile_ttis(ranenv_handle h, int64_t *n_ttis);
 
 /* Batch partitions: envs are independent, so the batch can be stepped as n_parts contiguous ranges, each by its own
  * launch on its own (handle-owned) HIP stream.  A launch has a ramp and a tail during which CUs idle; with partitions
@@ -287,7 +290,11 @@ int ranenv_set_partitions(ranenv_handle h, int32_t n_parts);
 /* n_steps TTIs under the device policy (the reference's MARR / MAPF evaluation loop, simu.py:555-566, where no learner
  * sits between two TTIs), enqueued in one call: per TTI the same launches as ranenv_step, but the caller's stream is
  * joined only before the first and after the last TTI, so that with partitions range k's TTI t+1 follows its own
- * TTI t directly.  The outputs hold the last TTI's values.  Needs a device policy and bound pools / generator. */
+ * TTI t directly.  The outputs hold the last TTI's values.  Needs a device policy and bound pools / generator.
+ * Where nothing has to happen between two TTIs (no head kernel bound; with auto-reset: no episode of the batch ends),
+ * one launch takes its envs through several of them -- up to a quarter of n_steps, at most 10: the workgroup steps
+ * its env again from the state it has just written instead of ending and being launched again.  Results are the
+ * same bit for bit. */
 int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *dev_obs_inter, float *dev_obs_intra,
                    double *dev_reward, uint8_t *dev_done, void *stream);
 /* With auto-reset enabled (ranenv_set_autoreset below) the rollout runs through episode ends: an env whose episode

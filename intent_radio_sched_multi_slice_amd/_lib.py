@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranenv_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
 INTRA_RR, INTRA_PF, INTRA_MT, INTRA_PER_SLICE = 0, 1, 2, 255
 F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK = 0x1, 0x2, 0x4
@@ -20,7 +20,7 @@ SE_STREAM, SE_GATHER = 0, 1
 EXPORTS = (
     "ranenv_last_error", "ranenv_abi_version", "ranenv_create", "ranenv_destroy",
     "ranenv_load_scenarios", "ranenv_bind_se_pool", "ranenv_bind_traffic_pool", "ranenv_set_episodes",
-    "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_profile_begin", "ranenv_profile_end",
+    "ranenv_set_policy", "ranenv_reset", "ranenv_step", "ranenv_step_dense", "ranenv_profile_begin", "ranenv_profile_end", "ranenv_profile_ttis",
     "ranenv_get_views",
     "ranenv_launch_info", "ranenv_se_from_power", "ranenv_bind_head_outputs", "ranenv_set_slice_usecase",
     "ranenv_set_traffic_generator", "ranenv_set_max_steps", "ranenv_set_episode_table", "ranenv_set_autoreset",
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     lib.ranenv_step_dense.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     lib.ranenv_profile_begin.argtypes = [C.c_void_p]
     lib.ranenv_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.ranenv_profile_ttis.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.ranenv_get_views.argtypes = [C.c_void_p, C.POINTER(Views)]
     lib.ranenv_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ranenv_se_from_power.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]

@@ -504,10 +504,12 @@ class BatchedRanEnv:
         self._check(self._lib.ranenv_profile_begin(self._h), "ranenv_profile_begin")
 
     def profile_end(self) -> Dict[str, float]:
-        """Average duration in ms of the step-kernel launches since profile_begin: {'step', 'n_launches'}."""
-        ms, n = C.c_double(), C.c_int32()
+        """Average duration in ms of the step-kernel launches since profile_begin: {'step', 'n_launches', 'n_ttis'}
+        (inside rollout() a launch may cover several TTIs: n_ttis / n_launches of them on average)."""
+        ms, n, nt = C.c_double(), C.c_int32(), C.c_int64()
         self._check(self._lib.ranenv_profile_end(self._h, C.byref(ms), C.byref(n)), "ranenv_profile_end")
-        return {"step": ms.value, "n_launches": n.value}
+        self._check(self._lib.ranenv_profile_ttis(self._h, C.byref(nt)), "ranenv_profile_ttis")
+        return {"step": ms.value, "n_launches": n.value, "n_ttis": nt.value}
 
     def set_partitions(self, n_parts: int):
         """Step the batch as ``n_parts`` contiguous ranges of envs, each by its own launch on its own stream

@@ -33,6 +33,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
            "-ffp-contract=off",     # numpy rounds a*b and +c separately; fma() is written out where it is exact
            "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",   # the kernel's few atomic adds come from one lane each
+           # no hoisting at machine level: around the step kernel's per-TTI loop it parks a dozen constants in VGPRs for the
+           # whole launch and spills to make room (96 VGPRs are the budget of 5 waves per SIMD); without it: no spills
+           "-mllvm", "-disable-machine-licm",
            "-I", os.path.join(REPO, "include"), SRC, "-o", OUT + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -137,6 +137,7 @@ struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
     long long BU, NSU, NSL;   // slab strides: B*U, n_scenarios*U, n_scenarios*S*16
     int e0;   // first env of this launch
+    int n_tti;       // TTIs this launch steps every env through (>= 1; more than one only inside ranenv_rollout)
     int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
     int compact;     // step only the UEs that are in a slice (lanes are ordered slice members first): waves without one leave
                      // at once.  Set by the host when it is exact: UEs outside every slice get no traffic (see idle_traffic_ok)
@@ -315,7 +316,8 @@ DEVFN RowPlan make_row_plan(int n)
 }
 
 #ifndef RANENV_SE_DEPTH
-#define RANENV_SE_DEPTH 1
+#define RANENV_SE_DEPTH 2          /* 8-row groups of the SE tile in flight per lane in the lean streaming kernel (step / reset at row
+                                      widths 8 and 10: 96 VGPRs without spills; the dense-mask and 16-wide builds keep 1) */
 #endif
 #ifndef RANENV_SE_RING
 #define RANENV_SE_RING 0           /* > 0: the lean streaming kernel keeps its SE queue in LDS, this many 8-row groups per wave */
@@ -708,13 +710,13 @@ template <int NP> DEVFN double *srow(SharedCore<NP> &sh, int s, int k) { return 
 // in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
 // in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
 // slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
-template <int NP>
-DEVFN void alloc_front(const KP &p, SharedCore<NP> &sh, int e, int hlen, bool have, int slc, int pos,
+template <int NP, typename P>
+DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen, bool have, int slc, int pos,
                        int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out)
 {
     auto &xs = sh.xr;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    const int tid = threadIdx.x, S = p.S;
+    const int S = p.S;
     const bool mapf = p.scores == nullptr && p.policy == RANENV_POLICY_MAPF;
     const int sl = have ? slc : 0;                 // idle threads read row 0 and write nothing
     double *r0 = srow(sh, sl, 0), *r1 = srow(sh, sl, 1), *r2 = srow(sh, sl, 2), *r3 = srow(sh, sl, 3);
@@ -909,15 +911,18 @@ DEVFN void alloc_front(const KP &p, SharedCore<NP> &sh, int e, int hlen, bool ha
 // The kernel body, instantiated per build (see the kernels behind it): NQ = groups of 8 SE loads in flight per lane;
 // GATHER = the SE gather mode (the tile's per-UE mean from the sidecar, the masked sum by gather_part from the UE-major
 // copy; p.se_pool / p.se_stride then describe that copy) instead of streaming the whole RB-major tile.
-template <int MODE, int NQ, bool GATHER, int NP>
-DEVFN void step_body(const KP &p)
+template <int MODE, int NQ, bool GATHER, int NP, typename P>
+DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
 {
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     __shared__ SharedCore<NP> sh;
     auto &xr = sh.xr;
-    const int e = p.e0 + blockIdx.x;
-    const int tid = threadIdx.x;
-    if (p.env_mask != nullptr && p.env_mask[e] == 0) return;  // uniform per workgroup
+    int e_ = p.e0 + blockIdx.x, tid_ = threadIdx.x;
+    // (opaque to the optimiser: inside step_loop nothing derived from them is carried from one TTI to the next in registers)
+    asm volatile("" : "+s"(e_));
+    asm volatile("" : "+v"(tid_));
+    const int e = e_, tid = tid_;
+    if (p.env_mask != nullptr && p.env_mask[e] == 0) return true;  // uniform per workgroup
     const int S = p.S, U = p.U, R = p.R, D = p.D, Us = p.Us;
     const int W = 2 * Us + 9;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -975,7 +980,7 @@ DEVFN void step_body(const KP &p)
     const int slc = TB_ue_slice(p)[tu], ue_pos = TB_ue_pos(p)[tu];
     const int pkt_size = TB_ue_pkt_size(p)[tu], max_pkts = TB_ue_max_pkts(p)[tu], max_age = TB_ue_max_age(p)[tu];
     const bool act = tid < U && !(compact && slc < 0);
-    if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return;     // (wave 0 stays: it runs the slice roles)
+    if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;     // (wave 0 stays: it runs the slice roles)
     const size_t su = (size_t)e * U + u;
     const int ptot = uni(ST_push_total(p)[e]);      // window pushes of this env so far (wraps; only differences are used)
     const int cmark = uni(ST_clear_mark(p)[e]);     // index of the first push behind the last clearing of the window
@@ -985,8 +990,9 @@ DEVFN void step_body(const KP &p)
     double sem_prev = 0.0;
     if (MODE != MODE_RESET) total = ST_queue_pkts(p)[su];
     if (!clear_hist) win_sent = ST_win_sent(p)[su];
-    int32_t *rs = ST_ring_sent(p) + ((size_t)e * D + npush) * U + u;
-    int32_t *rd = ST_ring_drop(p) + ((size_t)e * D + npush) * U + u;
+    // (this push's slots of the two rings: the addresses are formed where they are used, not carried through the step)
+    auto ring_s = [&]() { return ST_ring_sent(p) + ((size_t)e * D + npush) * U + u; };
+    auto ring_d = [&]() { return ST_ring_drop(p) + ((size_t)e * D + npush) * U + u; };
     int old_s = 0, old_d = 0;
     double traffic = 0.0;
     const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
@@ -996,7 +1002,7 @@ DEVFN void step_body(const KP &p)
             front = ST_front(p)[su]; front_rem = ST_front_rem(p)[su]; fifo = ST_fifo(p)[su];
         }
         if (!clear_hist) { win_drop = ST_win_dropped(p)[su]; lastp = ST_last_push(p)[su]; }
-        if (hlen == D) { old_s = *rs; old_d = *rd; }
+        if (hlen == D) { old_s = *ring_s(); old_d = *ring_d(); }
         if (MODE != MODE_RESET && !gen_traffic)
             traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
     };
@@ -1052,7 +1058,7 @@ DEVFN void step_body(const KP &p)
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
     if (MODE == MODE_STEP && !pre)
-        alloc_front<NP>(p, sh, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
+        alloc_front<NP>(p, sh, tid, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
                     rb_start, rb_count, ST_policy_scores(p));
     RANENV_STAMP(2);
 
@@ -1192,7 +1198,7 @@ DEVFN void step_body(const KP &p)
         }
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
         win_sent += sent - old_s; win_drop += dropped - old_d;
-        *rs = (int32_t)sent; *rd = (int32_t)dropped;
+        *ring_s() = (int32_t)sent; *ring_d() = (int32_t)dropped;
         ST_last_push(p)[su] = ptot + 1;
         ST_queue_pkts(p)[su] = total; ST_queue_age_sum(p)[su] = sum_age;
         ST_front(p)[su] = front; ST_front_rem(p)[su] = front_rem; ST_fifo(p)[su] = fifo;
@@ -1493,18 +1499,43 @@ DEVFN void step_body(const KP &p)
     if (late) {
         wg_sync();                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
-        alloc_front<NP>(p, sh, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
+        alloc_front<NP>(p, sh, tid, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
                     ns, nc, ST_next_scores(p));
         if (act) { ST_next_rb_start(p)[su] = ns; ST_next_rb_count(p)[su] = nc; }
     }
     if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
     RANENV_STAMP(8);
+    return false;
+}
+
+// Several TTIs of one env in one launch (ranenv_rollout with a device policy, no episode end in between): the workgroup
+// steps its env again as soon as it is done, from the state it has just written (its own CU's L1 / L2 hold it), instead
+// of ending and being launched again.  Between TTIs: every store of the workgroup is out and visible to its other
+// waves (__syncthreads = wait for the wave's memory operations + barrier; the waves of a workgroup share their CU's L1).
+template <int MODE, int NQ, bool GATHER, int NP>
+DEVFN void step_loop(const KP &p)
+{
+    if constexpr (MODE == MODE_STEP) {
+        // Every TTI reads the kernel's arguments in place, through a pointer the optimiser cannot see through: nothing
+        // derived from them is hoisted out of the loop and carried (= spilled) across a whole TTI.
+        typedef const __attribute__((address_space(4))) KP *kp_const_t;
+        const int n = p.n_tti;
+        for (int k = 0; k < n; k++) {
+            kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kc));
+            if (step_body<MODE, NQ, GATHER, NP>(*kc)) return;
+            if (k + 1 < n) __syncthreads();
+        }
+    } else {
+        step_body<MODE, NQ, GATHER, NP>(p);
+    }
 }
 #undef COLD
 
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
-// 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 8 SE loads in flight per lane -- occupancy hides more latency
-// than a deeper queue (measured, profiles/r02_ab_log.txt).  A small batch is resident at once whatever the register
+// 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 16 SE loads in flight per lane (8 until the build stopped hoisting
+// at machine level, which freed the registers for the second group) -- occupancy hides more latency than a still deeper
+// queue (measured, profiles/r02_ab_log.txt, r03_ab_log.txt).  A small batch is resident at once whatever the register
 // count, so it takes the build with 128 VGPRs and 32 loads in flight.
 #ifndef RANENV_WAVES_PER_EU
 #define RANENV_WAVES_PER_EU 5      /* experiment knob: waves per SIMD of the lean build (0 = compiler's choice) */
@@ -1517,12 +1548,12 @@ DEVFN void step_body(const KP &p)
 template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
-    step_body<MODE, RANENV_SE_RING ? -RANENV_SE_RING : RANENV_SE_DEPTH, false, NP>(p);
+    step_loop<MODE, RANENV_SE_RING ? -RANENV_SE_RING : ((MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH), false, NP>(p);
 }
 template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
 {
-    step_body<MODE, RANENV_SE_DEPTH_SMALL, false, NP>(p);
+    step_loop<MODE, RANENV_SE_DEPTH_SMALL, false, NP>(p);
 }
 // The SE gather build (ranenv_set_se_mode): no tile stream, so no queue registers; one build for every batch size.
 #ifndef RANENV_GATHER_WAVES_PER_EU
@@ -1530,7 +1561,7 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4,
 #endif
 template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_GATHER_WAVES_PER_EU, RANENV_GATHER_WAVES_PER_EU)))
-ranenv_core_kernel_gather(const KP p) { step_body<MODE, 1, true, NP>(p); }
+ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP>(p); }
 // Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
 
 // ---------------------------------------------------------------------------------------------
@@ -1866,6 +1897,8 @@ struct ranenv {
     int se_mode = RANENV_SE_STREAM;
     double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
     // compact steps (KP::compact): allowed while UEs outside every slice provably receive no traffic
+    int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
+    long long prof_ttis = 0;       // TTIs covered by the launches timed since ranenv_profile_begin
     bool compact_enabled = true, idle_check_dirty = true, pool_idle_zero = false, table_idle_zero = false;
     bool idle_state_clean = true;               // no step so far can have given an idle UE packets (else: full width until a full reset)
     int *d_violations = nullptr;
@@ -2021,6 +2054,7 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         }
         ev0 = h->prof_ev[h->prof_used]; ev1 = h->prof_ev[h->prof_used + 1];
         h->prof_used += 2;
+        h->prof_ttis += MODE == MODE_STEP ? kp.n_tti : 1;
     }
     switch (h->np) {
     case 8: launch_kernels<MODE, 8>(h, kp, grid, block, stream, ev0, ev1, gather); break;
@@ -2113,6 +2147,7 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
 void finalize_kp(ranenv_handle h, KP &kp)
 {
     kp.alloc_gen = h->alloc_gen;
+    kp.n_tti = 1;
     if (kp.fixed_intra == RANENV_INTRA_PER_SLICE) kp.late = 0;
 }
 
@@ -2189,6 +2224,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
     kp.late = RANENV_LATE_DEFAULT;
     if (const char *cv = getenv("RANENV_COMPACT")) h->compact_enabled = atoi(cv) != 0;                     // experiment knob
+    if (const char *fv = getenv("RANENV_FUSE")) h->fuse = atoi(fv) < 0 ? 0 : (atoi(fv) > 64 ? 64 : atoi(fv));   // experiment knob
     if (const char *lv = getenv("RANENV_LATE")) kp.late = atoi(lv) < 0 ? 0 : (atoi(lv) > 2 ? 2 : atoi(lv));   // experiment knob
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
     kp.norm_traffic = cfg->norm_traffic; kp.norm_ues = cfg->norm_ues; kp.norm_se = cfg->norm_se;
@@ -2595,7 +2631,14 @@ int ranenv_profile_begin(ranenv_handle h)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    h->prof_used = 0; h->prof_on = true;
+    h->prof_used = 0; h->prof_ttis = 0; h->prof_on = true;
+    return RANENV_OK;
+}
+
+int ranenv_profile_ttis(ranenv_handle h, int64_t *n_ttis)
+{
+    if (!h || !n_ttis) return fail(h, RANENV_E_INVALID, "null argument");
+    *n_ttis = (int64_t)h->prof_ttis;
     return RANENV_OK;
 }
 
@@ -2674,14 +2717,32 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
         kpr.head_reward = nullptr;               // the terminal transition's head rewards stay, like reward / done
     }
     const bool follow = h->ar_on;
-    for (int i = 0; i < n_steps; i++) {
-        const hipError_t e = for_partitions(h, stream, i == 0, i == n_steps - 1, [&](int e0, int n, hipStream_t s) -> hipError_t {
+    // A launch takes its envs through several TTIs where nothing has to happen in between (see step_loop): no head kernel
+    // behind every step, and -- with auto-reset -- no episode end before the launch's last TTI.  How many: a quarter of
+    // the rollout, at most 10 (measured, profiles/r03_ab_log.txt: longer launches gain nothing more and lengthen the
+    // drain at the rollout's end, where the workgroups that waited for a free slot run last and alone).
+    int fuse = h->fuse > 0 ? h->fuse : (n_steps / 4 < 1 ? 1 : (n_steps / 4 > 10 ? 10 : n_steps / 4));
+    if (kp.head_obs || kp.head_reward) fuse = 1;
+    auto max_steps_of = [&](int b) { return h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b]; };
+    for (int i = 0; i < n_steps; i += kp.n_tti) {
+        const int left = n_steps - i;
+        int n_tti = left < fuse ? left : fuse;
+        if (follow && n_tti > 1) {
+            int to_end = n_tti;                  // TTIs until the first episode of the batch ends (that TTI included)
+            for (int b = 0; b < h->cfg.batch; b++) {
+                const int d = max_steps_of(b) - steps[(size_t)b];
+                if (d < to_end) to_end = d;
+            }
+            n_tti = to_end < 1 ? 1 : to_end;
+        }
+        kp.n_tti = n_tti;
+        const hipError_t e = for_partitions(h, stream, i == 0, i + kp.n_tti >= n_steps, [&](int e0, int n, hipStream_t s) -> hipError_t {
             hipError_t le = launch_range<MODE_STEP>(h, kp, e0, n, s);
             if (le != hipSuccess || !follow) return le;
             bool any = false;
             for (int b = e0; b < e0 + n; b++) {
-                const int32_t m = h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b];
-                if (++steps[(size_t)b] >= m) { any = true; steps[(size_t)b] = 0; }
+                steps[(size_t)b] += kp.n_tti;
+                if (steps[(size_t)b] >= max_steps_of(b)) { any = true; steps[(size_t)b] = 0; }
             }
             if (!any) return hipSuccess;
             AdvanceArgs a = adv; a.e0 = e0;

@@ -45,7 +45,7 @@ args = types.SimpleNamespace(steps=K, warmup=2, config=2, traces=4, trace_len=5)
 n0 = env.n
 times = bench.timed_blocks(lambda: [env.step() for _ in range(K)], lambda: None, dist.barrier, max_over_ranks, sample_s=0.05)
 assert len(times) >= 2 and (env.n - n0) == K * (len(times) + 1)
-line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, [elapsed], 0.5, 2 * K, 2, None, summarize(gathered),
+line = bench.build_line(args, world, B, "stub", (S, U, 9), 1000, [elapsed], {"step": 0.5, "n_launches": 2 * K, "n_ttis": 2 * K}, 2, None, summarize(gathered),
                         extras={"pipelined_step": bench.block_stats(times, B * world * K, K)})
 # one file per rank: two ranks printing at once can interleave on the launcher's pipe
 with open(os.path.join(os.environ["OUT_DIR"], f"rank{rank}.txt"), "w") as f:

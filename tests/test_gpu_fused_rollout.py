@@ -1,0 +1,134 @@
+"""ranenv_rollout's launches that take their envs through several TTIs (step_loop in csrc/ranenv.hip; include/ranenv.h
+"ranenv_rollout"): bit for bit what one launch per TTI leaves behind -- state, observations, rewards, done flags, episode
+metrics -- with and without partitions, in both SE modes, across device auto-resets (launches end at the TTI at which an
+episode of the batch ends), with per-env episode lengths, with the traffic drawn on the device.  (Against the oracle the
+rollout is checked elsewhere, e.g. tests/test_gpu_rollout_and_partitions.py, which now runs fused by default.)
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.test_gpu_se_gather_and_ranges import _bench_like, _short_episode_setup
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _same(a, b, what=""):
+    for k, x in a.views().items():
+        assert torch.equal(x, b.views()[k]), (what, k)
+    assert torch.equal(a.obs_inter, b.obs_inter) and torch.equal(a.obs_intra, b.obs_intra), what
+    assert torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), what
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+@pytest.mark.parametrize("parts", [1, 3])
+def test_fused_rollouts_equal_one_launch_per_tti(monkeypatch, se_mode, parts):
+    """BASELINE configs[2]'s shape, 512 envs: rollouts of 1, 2, 7, 23 and 45 TTIs (launches of up to 1, 1, 1, 5 and 10
+    TTIs, the last one of a rollout shorter) against the same rollouts with RANENV_FUSE=1."""
+    _need_gpu()
+    a = _bench_like(512, se_mode == "gather")
+    monkeypatch.setenv("RANENV_FUSE", "1")
+    b = _bench_like(512, se_mode == "gather")
+    monkeypatch.delenv("RANENV_FUSE")
+    for wl in (a, b):
+        wl.env.enable_metrics(0)
+        wl.env.reset()
+        wl.env.set_partitions(parts)
+    for K in (1, 2, 7, 23, 45):
+        a.env.rollout(K); b.env.rollout(K)
+        torch.cuda.synchronize()
+        _same(a.env, b.env, (se_mode, parts, K))
+        assert torch.equal(a.env.episode_metrics()["running"], b.env.episode_metrics()["running"]), K
+    assert int(a.env.views()["step_number"][0]) == 1 + 2 + 7 + 23 + 45
+    a.env.close(); b.env.close()
+
+
+def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
+    """The profile counters: a rollout of 40 TTIs over 3 partitions is 3 x 4 launches of 10 TTIs (4 x 10 launch-TTIs per
+    partition); with RANENV_FUSE=1 it is 3 x 40 launches of one."""
+    _need_gpu()
+    a = _bench_like(96, False)
+    a.env.reset(); a.env.set_partitions(3)
+    a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
+    assert (pa["n_launches"], pa["n_ttis"]) == (12, 120)
+    a.env.profile_begin(); a.env.rollout(23); pa = a.env.profile_end()          # 5 + 5 + 5 + 5 + 3
+    assert (pa["n_launches"], pa["n_ttis"]) == (15, 69)
+    a.env.profile_begin(); a.env.step(); pa = a.env.profile_end()
+    assert (pa["n_launches"], pa["n_ttis"]) == (3, 3)
+    a.env.close()
+    monkeypatch.setenv("RANENV_FUSE", "1")
+    b = _bench_like(96, False)
+    b.env.reset(); b.env.set_partitions(3)
+    b.env.profile_begin(); b.env.rollout(40); pb = b.env.profile_end()
+    assert (pb["n_launches"], pb["n_ttis"]) == (120, 120)
+    b.env.close()
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+@pytest.mark.parametrize("staggered", [False, True])
+def test_fused_rollouts_across_device_autoresets(monkeypatch, se_mode, staggered):
+    """Episodes of 13 TTIs with the scenario changing at every reset.  In lock step the launches run up to the TTI at which
+    the episodes end (13 = 10 + 3 inside a rollout of 40 ...), the advance + reset launches follow, the next launch starts
+    the new episodes; with per-env episode lengths between 5 and 13 some episode ends almost every TTI and the launches
+    shrink accordingly.  Same state, observations, episode numbers and per-episode metric sums as one launch per TTI."""
+    _need_gpu()
+    envs = []
+    for fuse in (None, "1"):
+        if fuse:
+            monkeypatch.setenv("RANENV_FUSE", fuse)
+        env, tabs, se_pool, trf, start, dims = _short_episode_setup(48, 13, False, se_mode)
+        if fuse:
+            monkeypatch.delenv("RANENV_FUSE")
+        if staggered:
+            env.set_max_steps(5 + (np.arange(48) * 7) % 9)
+        env.enable_metrics(8)
+        env.reset()
+        env.set_partitions(2)
+        envs.append(env)
+    a, b = envs
+    n_launch = []
+    for K in (40, 9, 31):
+        a.profile_begin(); a.rollout(K); pa = a.profile_end()
+        b.rollout(K)
+        torch.cuda.synchronize()
+        n_launch.append(pa["n_launches"])
+        for name, x in a.views().items():
+            if name != "se_mean":            # (compact steps: not kept up for UEs outside every slice)
+                assert torch.equal(x, b.views()[name]), (K, name)
+        assert torch.equal(a.obs_inter, b.obs_inter) and torch.equal(a.obs_intra, b.obs_intra) and torch.equal(a.reward, b.reward), K
+        ma, mb = a.episode_metrics(), b.episode_metrics()
+        for k in ("running", "episode_log", "episodes_done"):
+            assert torch.equal(ma[k], mb[k]), (K, k)
+    if not staggered:
+        # step launches only (the reset launches are timed too): 40 TTIs from step 0 = 10 + 3 | 10 + 3 | 10 + 3 | 1
+        assert n_launch[0] < 2 * 40
+    assert int(a.views()["episode_number"].max()) >= 5
+    a.close(); b.close()
+
+
+def test_fused_rollout_with_the_traffic_drawn_on_the_device(monkeypatch):
+    """The Philox / Poisson generator is keyed by (env, episode, TTI, UE): a launch that runs several TTIs draws what the
+    same TTIs draw one launch at a time."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    envs = []
+    for fuse in (None, "1"):
+        if fuse:
+            monkeypatch.setenv("RANENV_FUSE", fuse)
+        wl, _ = make_bench_workload(2, torch.device("cuda", 0), batch=256, n_traces=8, trace_len=30, traffic="philox")
+        if fuse:
+            monkeypatch.delenv("RANENV_FUSE")
+        wl.env.reset(); wl.env.set_partitions(3)
+        envs.append(wl.env)
+    a, b = envs
+    a.rollout(48); b.rollout(48)
+    torch.cuda.synchronize()
+    _same(a, b, "philox")
+    assert int(a.views()["pkt_incoming"].sum()) > 0
+    a.close(); b.close()
