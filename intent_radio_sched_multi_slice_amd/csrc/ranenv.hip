@@ -141,9 +141,9 @@ struct KP {
     int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
     int compact;     // step only the UEs that are in a slice (lanes are ordered slice members first): waves without one leave
                      // at once.  Set by the host when it is exact: UEs outside every slice get no traffic (see idle_traffic_ok)
-    int late;        // 0: every step allocates at its head; 1: a hashed half of the envs, 2: all envs allocate for the next
-                     // TTI at the end of the step (device policy only), so that heads and tails of workgroups differ in
-                     // what they load the CU with
+    int late;        // 0 (default): every step allocates at its head; 1: a hashed half of the envs, 2: all envs allocate for the
+                     // next TTI at the end of the step (device policy only), so that heads and tails of workgroups differ in
+                     // what they load the CU with (RANENV_LATE; the default while a launch was one TTI)
     double bw_hz, bw_per_rb, over, norm_traffic, norm_ues, norm_se;
     Tables tab;
     State st;
@@ -340,8 +340,12 @@ DEVFN RowPlan make_row_plan(int n)
 #ifndef RANENV_METRICS
 #define RANENV_METRICS 1           /* 0 compiles the episode-metric sums out (A/B of their cost only) */
 #endif
+#ifndef RANENV_LATE_BUILT
+#define RANENV_LATE_BUILT 1        /* 0 compiles the allocation-ahead path out */
+#endif
 #ifndef RANENV_LATE_DEFAULT
-#define RANENV_LATE_DEFAULT 1
+#define RANENV_LATE_DEFAULT 0      /* (1 until launches ran several TTIs: their workgroups drift apart by themselves, and allocating
+                                      ahead only costs its round trip through HBM -- rollout 62.1 -> 61.2, gather 37.8 -> 36.6 us per TTI) */
 #endif
 #ifndef RANENV_SE_DEPTH_SMALL
 #define RANENV_SE_DEPTH_SMALL 4   /* the same for batches that do not fill the CUs anyway (step kernel built for 4 waves per SIMD) */
@@ -706,6 +710,18 @@ DEVFN void wg_sync()
 
 template <int NP> DEVFN double *srow(SharedCore<NP> &sh, int s, int k) { return &sh.rows[s][k * NP]; }
 
+// Element of a per-env row of a global array: the array's base and the env's row (`row_bytes`, wave-uniform: scalar
+// arithmetic, a pair of SGPRs) + the lane's own byte offset in ONE VGPR -- the "saddr" form of global_load / global_store --
+// instead of a 64-bit address per array and lane (a VGPR pair and two vector adds each; the step kernel touches ~30 arrays).
+// The row address is made opaque where it is used: otherwise the optimiser forms array + row + lane once, as a 64-bit vector
+// value, and carries it from the load at the top of the step to the store at its end.
+template <typename T> DEVFN T &row_at(T *array, size_t row_bytes, unsigned lane_bytes)
+{
+    char *row = (char *)array + row_bytes;
+    asm volatile("" : "+s"(row));
+    return *(T *)(row + lane_bytes);
+}
+
 // Role (0).  Called by every thread of the workgroup (it contains barriers); `have` = this thread's UE is
 // in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
 // in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
@@ -768,10 +784,10 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             }
             wave_sync();
         } else if (ok1) {
-            score = p.scores ? p.scores[(size_t)e * S + s1] : (nues1 > 0 ? 1.0 : -1.0);              // marr.py:40-47
+            score = p.scores ? row_at(p.scores, (size_t)e * S * 8, (unsigned)s1 * 8u) : (nues1 > 0 ? 1.0 : -1.0);   // marr.py:40-47
         }
 #if RANENV_DIAG != 9
-        if (ok1) scores_out[(size_t)e * S + s1] = score;
+        if (ok1) row_at(scores_out, (size_t)e * S * 8, (unsigned)s1 * 8u) = score;
 #endif
         if (tid < GRP) xs[3][s1] = score;
         wave_sync();
@@ -975,63 +991,73 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
     // of the scenarios have at most 64 UEs in slices, and their envs run one wave instead of two.
     const bool compact = MODE == MODE_STEP && p.compact != 0;
     const int lane = tid < U ? tid : U - 1;
-    const size_t tu = (size_t)sc * U + lane + (compact ? (size_t)0 : (size_t)6 * (size_t)p.NSU);
-    const int u = compact ? TB_lane_ue(p)[tu] : lane;      // (set 1 is the identity: no load, and the state loads need not wait for it)
-    const int slc = TB_ue_slice(p)[tu], ue_pos = TB_ue_pos(p)[tu];
-    const int pkt_size = TB_ue_pkt_size(p)[tu], max_pkts = TB_ue_max_pkts(p)[tu], max_age = TB_ue_max_age(p)[tu];
+    // (addressing: see row_at -- a uniform row per array, the lane's byte offset in one register)
+    const size_t tb_row = ((size_t)sc * U + (compact ? (size_t)0 : (size_t)6 * (size_t)p.NSU)) * 4;
+    const unsigned lane4 = (unsigned)lane * 4u;
+#define TBL(f) row_at(TB_##f(p), tb_row, lane4)
+    const int u = compact ? TBL(lane_ue) : lane;      // (set 1 is the identity: no load, and the state loads need not wait for it)
+    const int slc = TBL(ue_slice), ue_pos = TBL(ue_pos);
+    const int pkt_size = TBL(ue_pkt_size), max_pkts = TBL(ue_max_pkts), max_age = TBL(ue_max_age);
+#undef TBL
     const bool act = tid < U && !(compact && slc < 0);
     if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;     // (wave 0 stays: it runs the slice roles)
     const size_t su = (size_t)e * U + u;
+    const size_t er4 = (size_t)e * U * 4, er8 = (size_t)e * U * 8;      // this env's row of a per-UE array of 4- / 8-byte elements
+    const unsigned u4 = (unsigned)u * 4u, u8 = (unsigned)u * 8u;
+#define UE4(f) row_at(ST_##f(p), er4, u4)
+#define UE8(f) row_at(ST_##f(p), er8, u8)
     const int ptot = uni(ST_push_total(p)[e]);      // window pushes of this env so far (wraps; only differences are used)
     const int cmark = uni(ST_clear_mark(p)[e]);     // index of the first push behind the last clearing of the window
     int lastp = ptot;                               // index behind this UE's last push
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     double sem_prev = 0.0;
-    if (MODE != MODE_RESET) total = ST_queue_pkts(p)[su];
-    if (!clear_hist) win_sent = ST_win_sent(p)[su];
+    if (MODE != MODE_RESET) total = UE4(queue_pkts);
+    if (!clear_hist) win_sent = UE8(win_sent);
     // (this push's slots of the two rings: the addresses are formed where they are used, not carried through the step)
-    auto ring_s = [&]() { return ST_ring_sent(p) + ((size_t)e * D + npush) * U + u; };
-    auto ring_d = [&]() { return ST_ring_drop(p) + ((size_t)e * D + npush) * U + u; };
+    auto ring_s = [&]() { return &row_at(ST_ring_sent(p), ((size_t)e * D + npush) * U * 4, u4); };
+    auto ring_d = [&]() { return &row_at(ST_ring_drop(p), ((size_t)e * D + npush) * U * 4, u4); };
     int old_s = 0, old_d = 0;
     double traffic = 0.0;
     const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
     auto rest_of_state = [&]() {
         if (MODE != MODE_RESET) {
-            sum_age = ST_queue_age_sum(p)[su];
-            front = ST_front(p)[su]; front_rem = ST_front_rem(p)[su]; fifo = ST_fifo(p)[su];
+            sum_age = UE8(queue_age_sum);
+            front = UE4(front); front_rem = UE4(front_rem); fifo = UE4(fifo);
         }
-        if (!clear_hist) { win_drop = ST_win_dropped(p)[su]; lastp = ST_last_push(p)[su]; }
+        if (!clear_hist) { win_drop = UE8(win_dropped); lastp = UE4(last_push); }
         if (hlen == D) { old_s = *ring_s(); old_d = *ring_d(); }
         if (MODE != MODE_RESET && !gen_traffic)
-            traffic = p.traffic_bits ? p.traffic_bits[su] : (double)p.trf_pool[((size_t)ep.trf_base + (size_t)trf_pos) * U + u];
+            traffic = p.traffic_bits ? row_at(p.traffic_bits, er8, u8)
+                                     : (double)row_at(p.trf_pool, ((size_t)ep.trf_base + (size_t)trf_pos) * U * 4, u4);
     };
 #if !RANENV_DEFER_STATE
     rest_of_state();
 #endif
-    if (MODE == MODE_STEP) sem_prev = ST_se_mean(p)[su];
+    if (MODE == MODE_STEP) sem_prev = UE8(se_mean);
     double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
-    if (GATHER) sem_tile = p.se_mean_pool[(size_t)tile_no * U + u];
+    if (GATHER) sem_tile = row_at(p.se_mean_pool, (size_t)tile_no * U * 8, u8);
     // the scenario's slice tables, parked in LDS below by wave 0 (the other waves may have left): up to two words per lane
     int st_si0 = 0, st_si1 = 0, st_pi0 = 0, st_pi1 = 0; double st_pf = 0.0, st_sf = 0.0;
     if (tid < WAVE) {
-        if (tid < S * 8) st_si0 = TB_slice_i32(p)[(size_t)sc * S * 8 + tid];
-        if (tid + WAVE < S * 8) st_si1 = TB_slice_i32(p)[(size_t)sc * S * 8 + tid + WAVE];
-        if (tid < S * 6) st_pi0 = TB_param_i32(p)[(size_t)sc * S * 6 + tid];
-        if (tid + WAVE < S * 6) st_pi1 = TB_param_i32(p)[(size_t)sc * S * 6 + tid + WAVE];
-        if (tid < S * 3) st_pf = TB_param_f64(p)[(size_t)sc * S * 3 + tid];
-        if (tid < S * 2) st_sf = TB_slice_f64(p)[(size_t)sc * S * 2 + tid];
+        const unsigned t4 = (unsigned)tid * 4u, t8 = (unsigned)tid * 8u;
+        if (tid < S * 8) st_si0 = row_at(TB_slice_i32(p), (size_t)sc * S * 32, t4);
+        if (tid + WAVE < S * 8) st_si1 = row_at(TB_slice_i32(p), (size_t)sc * S * 32, t4 + WAVE * 4u);
+        if (tid < S * 6) st_pi0 = row_at(TB_param_i32(p), (size_t)sc * S * 24, t4);
+        if (tid + WAVE < S * 6) st_pi1 = row_at(TB_param_i32(p), (size_t)sc * S * 24, t4 + WAVE * 4u);
+        if (tid < S * 3) st_pf = row_at(TB_param_f64(p), (size_t)sc * S * 24, t8);
+        if (tid < S * 2) st_sf = row_at(TB_slice_f64(p), (size_t)sc * S * 16, t8);
     }
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
-    if (MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
+    if (RANENV_LATE_BUILT && MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
 #if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8    /* ablations: 8 = no allocation and no obs tail; 10 = allocation + tail only; 6 = entry + stream only (ranges from the stored allocation, sums written out); 7 = no allocation */
     if (MODE == MODE_STEP) pre = true;
 #endif
     if (pre) {
-        rb_start = ST_next_rb_start(p)[su]; rb_count = ST_next_rb_count(p)[su];
+        rb_start = UE4(next_rb_start); rb_count = UE4(next_rb_count);
 #if RANENV_DIAG != 9
-        if (tid < S) ST_policy_scores(p)[(size_t)e * S + tid] = ST_next_scores(p)[(size_t)e * S + tid];
+        if (tid < S) row_at(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
 #endif
     }
     const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
@@ -1105,7 +1131,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
     bool prev_empty = total == 0;
     if (total != 0 && !((double)total > 2e-8 * (double)max_pkts)) prev_empty = d_isclose((double)total / (double)max_pkts, 0.0);
 #if RANENV_DIAG == 6
-    if (act) { ST_se_mean(p)[su] = my_full; ST_queue_age_sum(p)[su] = (long long)my_part; }
+    if (act) { UE8(se_mean) = my_full; UE8(queue_age_sum) = (long long)my_part; }
 #endif
 #if RANENV_DIAG == 6
     if (false) {
@@ -1147,10 +1173,10 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
             // packets) entries in arrival order.  ring[k] holds entry k of a circular list (head index +
             // entry count per UE); only TTIs that admitted packets make an entry, so expiring / draining
             // costs one load per consumed entry and never a scan.
-            int2 *ring = ST_age_ring(p) + (size_t)e * L * U + u;
+            int2 *ring_env = ST_age_ring(p) + (size_t)e * L * U;        // (uniform; entry k of this UE at [k * U + u])
             int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
             auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
-            auto load_head = [&]() { const int2 en = ring[(size_t)head * U]; front = en.x; front_rem = en.y; };
+            auto load_head = [&]() { const int2 en = row_at(ring_env, 0, (unsigned)(head * U + u) * 8u); front = en.x; front_rem = en.y; };
             if (nent > 0 && front == t - max_age - 1) {         // receive: the bin older than max_age expires
                 dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
                 front_rem = 0;
@@ -1163,7 +1189,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
             dropped += pkt_in - adm;
             if (adm > 0) {
                 int tail = head + nent; tail = tail >= L ? tail - L : tail;
-                ring[(size_t)tail * U] = make_int2(t, adm);
+                row_at(ring_env, 0, (unsigned)(tail * U + u) * 8u) = make_int2(t, adm);
                 if (nent == 0) { front = t; front_rem = adm; }
                 nent++;
                 total += adm;
@@ -1191,7 +1217,8 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
             if (ptot - q == D) { old_s = 0; old_d = 0; }         // the slot of this push is among them: it will hold a zero
             for (; q != ptot; q++) {
                 int slot = npush - (ptot - q); slot += slot < 0 ? D : 0;
-                int32_t *qs = ST_ring_sent(p) + ((size_t)e * D + slot) * U + u, *qd = ST_ring_drop(p) + ((size_t)e * D + slot) * U + u;
+                const unsigned so = (unsigned)(slot * U + u) * 4u;
+                int32_t *qs = &row_at(ST_ring_sent(p), (size_t)e * D * U * 4, so), *qd = &row_at(ST_ring_drop(p), (size_t)e * D * U * 4, so);
                 if (q - cmark >= D) { win_sent -= *qs; win_drop -= *qd; }
                 *qs = 0; *qd = 0;
             }
@@ -1199,18 +1226,18 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
         win_sent += sent - old_s; win_drop += dropped - old_d;
         *ring_s() = (int32_t)sent; *ring_d() = (int32_t)dropped;
-        ST_last_push(p)[su] = ptot + 1;
-        ST_queue_pkts(p)[su] = total; ST_queue_age_sum(p)[su] = sum_age;
-        ST_front(p)[su] = front; ST_front_rem(p)[su] = front_rem; ST_fifo(p)[su] = fifo;
-        ST_win_sent(p)[su] = win_sent; ST_win_dropped(p)[su] = win_drop;
-        ST_pkt_effective_thr(p)[su] = (int32_t)sent; ST_dropped_pkts(p)[su] = (int32_t)dropped;
+        UE4(last_push) = ptot + 1;
+        UE4(queue_pkts) = total; UE8(queue_age_sum) = sum_age;
+        UE4(front) = front; UE4(front_rem) = front_rem; UE4(fifo) = fifo;
+        UE8(win_sent) = win_sent; UE8(win_dropped) = win_drop;
+        UE4(pkt_effective_thr) = (int32_t)sent; UE4(dropped_pkts) = (int32_t)dropped;
         if (!(COLD(flags) & RANENV_F_NO_RAW_OUTPUT)) {
-            ST_pkt_incoming(p)[su] = (int32_t)pkt_in; ST_pkt_throughputs(p)[su] = (int32_t)pkt_thr;
+            UE4(pkt_incoming) = (int32_t)pkt_in; UE4(pkt_throughputs) = (int32_t)pkt_thr;
         }
         sent_u = sent; drop_u = dropped;
 
-        ST_se_mean(p)[su] = se_mean_new; sem_new = se_mean_new;
-        ST_rb_start(p)[su] = rb_start; ST_rb_count(p)[su] = rb_count;
+        UE8(se_mean) = se_mean_new; sem_new = se_mean_new;
+        UE4(rb_start) = rb_start; UE4(rb_count) = rb_count;
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
@@ -1396,7 +1423,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
         for (int m = 0; m < 3; m++) {
             if (am[m] > 0.0) { r = (cnt == 0 || sv[m] < r) ? sv[m] : r; cnt++; }
         }
-        if (COLD(reward)) COLD(reward)[(size_t)e * (S + 1) + s + 1] = cnt > 0 ? r : 0.0;
+        if (COLD(reward)) row_at(COLD(reward), (size_t)e * (S + 1) * 8, (unsigned)(s + 1) * 8u) = cnt > 0 ? r : 0.0;
         if (MODE == MODE_RESET) {
             ST_mask_inter(p)[(size_t)e * S + s] = (int8_t)active;
             for (int k = 0; k < Us; k++) ST_mask_intra(p)[((size_t)e * S + s) * Us + k] = k < n ? 1 : 0;
@@ -1480,11 +1507,11 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (COLD(obs_inter)) {
             float *dst = COLD(obs_inter) + (size_t)e * S * 10;
-            for (int i = tid; i < S * 10; i += WAVE) dst[i] = sh.ob_inter[i];
+            for (int i = tid; i < S * 10; i += WAVE) row_at(dst, 0, (unsigned)i * 4u) = sh.ob_inter[i];
         }
         if (COLD(obs_intra)) {
             float *dst = COLD(obs_intra) + (size_t)e * S * W;
-            for (int i = tid; i < S * W; i += WAVE) dst[i] = sh.ob_intra[i];
+            for (int i = tid; i < S * W; i += WAVE) row_at(dst, 0, (unsigned)i * 4u) = sh.ob_intra[i];
         }
     }
 #endif
@@ -1492,7 +1519,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
 
     // ---- (0') the next TTI's allocation, from the state this step leaves behind ----------------------
     bool late = false;
-    if (MODE == MODE_STEP) late = p.scores == nullptr && (p.late == 2 || (p.late == 1 && (((unsigned)e * 0x9E3779B1u) >> 16 & 1u)));
+    if (RANENV_LATE_BUILT && MODE == MODE_STEP) late = p.scores == nullptr && (p.late == 2 || (p.late == 1 && (((unsigned)e * 0x9E3779B1u) >> 16 & 1u)));
 #if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8
     if (MODE == MODE_STEP) late = false;
 #endif
@@ -1501,11 +1528,13 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
         int ns = 0, nc = 0;
         alloc_front<NP>(p, sh, tid, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
                     ns, nc, ST_next_scores(p));
-        if (act) { ST_next_rb_start(p)[su] = ns; ST_next_rb_count(p)[su] = nc; }
+        if (act) { UE4(next_rb_start) = ns; UE4(next_rb_count) = nc; }
     }
     if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
     RANENV_STAMP(8);
     return false;
+#undef UE4
+#undef UE8
 }
 
 // Several TTIs of one env in one launch (ranenv_rollout with a device policy, no episode end in between): the workgroup

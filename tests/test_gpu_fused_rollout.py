@@ -53,6 +53,7 @@ def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
     """The profile counters: a rollout of 40 TTIs over 3 partitions is 3 x 4 launches of 10 TTIs (4 x 10 launch-TTIs per
     partition); with RANENV_FUSE=1 it is 3 x 40 launches of one."""
     _need_gpu()
+    monkeypatch.delenv("RANENV_FUSE", raising=False)          # (the default policy, whatever knob the suite runs under)
     a = _bench_like(96, False)
     a.env.reset(); a.env.set_partitions(3)
     a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()

@@ -1,8 +1,3 @@
-for rep in 1 2; do
-for m in stream gather; do
-  export RANENV_SE_MODE=$m
-  for f in 1 2 3 5 0; do
-    echo "== $m FUSE=$f: $(RANENV_FUSE=$f timeout -k 10 100 python tools/kprobe.py 2>&1 | grep K= | tr '\n' ' ')"
-  done
-done
-done
+RANENV_LATE=2 RANENV_FUSE=3 timeout -k 10 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -2 | cut -c1-200 || exit 1
+RANENV_SE_MODE=gather RANENV_FUSE=7 timeout -k 10 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -2 | cut -c1-200 || exit 1
+RANENV_COMPACT=0 RANENV_FUSE=20 RANENV_ROW_WIDTH=16 timeout -k 10 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -2 | cut -c1-200 || exit 1
