@@ -520,8 +520,10 @@ class BatchedRanEnv:
 
     def rollout(self, n_steps: int):
         """``n_steps`` TTIs under the device policy enqueued in one call (MARR / MAPF evaluation runs): the launches of
-        ``n_steps`` calls of ``step()``, joined with the current stream only before the first and after the last TTI.
-        Returns the last TTI's (obs, reward, done)."""
+        ``n_steps`` calls of ``step()``, joined with the current stream only before the first and after the last TTI
+        -- except that one launch takes its envs through up to n_steps / 4 (at most 10) TTIs where nothing has to happen in
+        between (no head kernel; with auto-reset: up to the TTI at which an episode of the batch ends).  Same results bit
+        for bit.  Returns the last TTI's (obs, reward, done)."""
         if self._recorder is not None:
             raise RanEnvError("rollout() does not return between TTIs: the recorder needs step()")
         st = self._lib.ranenv_rollout(self._h, int(n_steps), *self._p_out,
