@@ -1927,6 +1927,7 @@ struct ranenv {
     double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
     // compact steps (KP::compact): allowed while UEs outside every slice provably receive no traffic
     int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
+    std::vector<int> fuse_first;   // override of the length of partition k's first launch of a rollout (RANENV_FUSE_FIRST=a,b,c)
     long long prof_ttis = 0;       // TTIs covered by the launches timed since ranenv_profile_begin
     bool compact_enabled = true, idle_check_dirty = true, pool_idle_zero = false, table_idle_zero = false;
     bool idle_state_clean = true;               // no step so far can have given an idle UE packets (else: full width until a full reset)
@@ -2253,6 +2254,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
     kp.late = RANENV_LATE_DEFAULT;
     if (const char *cv = getenv("RANENV_COMPACT")) h->compact_enabled = atoi(cv) != 0;                     // experiment knob
+    if (const char *ff = getenv("RANENV_FUSE_FIRST")) { for (const char *c = ff; *c;) { h->fuse_first.push_back(atoi(c)); while (*c && *c != ',') c++; if (*c) c++; } }
     if (const char *fv = getenv("RANENV_FUSE")) h->fuse = atoi(fv) < 0 ? 0 : (atoi(fv) > 64 ? 64 : atoi(fv));   // experiment knob
     if (const char *lv = getenv("RANENV_LATE")) kp.late = atoi(lv) < 0 ? 0 : (atoi(lv) > 2 ? 2 : atoi(lv));   // experiment knob
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
@@ -2753,24 +2755,49 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     int fuse = h->fuse > 0 ? h->fuse : (n_steps / 4 < 1 ? 1 : (n_steps / 4 > 10 ? 10 : n_steps / 4));
     if (kp.head_obs || kp.head_reward) fuse = 1;
     auto max_steps_of = [&](int b) { return h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b]; };
-    for (int i = 0; i < n_steps; i += kp.n_tti) {
-        const int left = n_steps - i;
-        int n_tti = left < fuse ? left : fuse;
-        if (follow && n_tti > 1) {
-            int to_end = n_tti;                  // TTIs until the first episode of the batch ends (that TTI included)
-            for (int b = 0; b < h->cfg.batch; b++) {
-                const int d = max_steps_of(b) - steps[(size_t)b];
-                if (d < to_end) to_end = d;
+    // Every partition walks through the n_steps TTIs in launches of its own: `pdone[k]` TTIs are enqueued for partition k.
+    const int np = h->n_parts > 1 ? h->n_parts : 1;
+    std::vector<int> pdone((size_t)np, 0), pn((size_t)np, 0);
+    auto part_of = [&](int e0) { for (int k = 0; k < np; k++) if (np > 1 && h->part_lo[k] == e0) return k; return 0; };
+    for (int round = 0;; round++) {
+        bool any_left = false, last = true;
+        for (int k = 0; k < np; k++) {
+            const int left = n_steps - pdone[(size_t)k];
+            int n_tti = left < fuse ? left : fuse;
+            if (round == 0 && fuse > 1 && np > 1) {
+                // The partitions' first launches differ in length, the one enqueued last (partition 0, on the caller's
+                // stream) starting with a single TTI: it is the one whose workgroups find the slots taken (4096 envs want
+                // 3738), and after one short launch its late starters are through instead of holding its chain up for a
+                // whole long one; from then on the partitions' launch boundaries no longer coincide (K = 20: -2 % streaming,
+                // -4 % gather; profiles/r03_ab_log.txt).  RANENV_FUSE_FIRST=a,b,c overrides (0 = the common length).
+                int first = k == 0 ? 1 : ((k & 1) ? (3 * fuse + 4) / 5 : fuse);
+                if (!h->fuse_first.empty()) first = (size_t)k < h->fuse_first.size() ? h->fuse_first[(size_t)k] : 0;
+                if (first > 0 && first < n_tti) n_tti = first;
             }
-            n_tti = to_end < 1 ? 1 : to_end;
+            if (follow && n_tti > 1) {
+                int to_end = n_tti;              // TTIs until the first episode of the partition ends (that TTI included)
+                const int lo = np > 1 ? h->part_lo[k] : 0, hi = np > 1 ? h->part_lo[k + 1] : h->cfg.batch;
+                for (int b = lo; b < hi; b++) {
+                    const int d = max_steps_of(b) - steps[(size_t)b];
+                    if (d < to_end) to_end = d;
+                }
+                n_tti = to_end < 1 ? 1 : to_end;
+            }
+            pn[(size_t)k] = n_tti > 0 ? n_tti : 0;
+            if (pn[(size_t)k] > 0) any_left = true;
+            if (pdone[(size_t)k] + pn[(size_t)k] < n_steps) last = false;
         }
-        kp.n_tti = n_tti;
-        const hipError_t e = for_partitions(h, stream, i == 0, i + kp.n_tti >= n_steps, [&](int e0, int n, hipStream_t s) -> hipError_t {
-            hipError_t le = launch_range<MODE_STEP>(h, kp, e0, n, s);
+        if (!any_left) break;
+        const hipError_t e = for_partitions(h, stream, round == 0, last, [&](int e0, int n, hipStream_t s) -> hipError_t {
+            const int n_tti = pn[(size_t)part_of(e0)];
+            if (n_tti == 0) return hipSuccess;                                    // this partition is through
+            KP kpk = kp;
+            kpk.n_tti = n_tti;
+            hipError_t le = launch_range<MODE_STEP>(h, kpk, e0, n, s);
             if (le != hipSuccess || !follow) return le;
             bool any = false;
             for (int b = e0; b < e0 + n; b++) {
-                steps[(size_t)b] += kp.n_tti;
+                steps[(size_t)b] += n_tti;
                 if (steps[(size_t)b] >= max_steps_of(b)) { any = true; steps[(size_t)b] = 0; }
             }
             if (!any) return hipSuccess;
@@ -2778,7 +2805,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
             hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
             return launch_range<MODE_RESET>(h, kpr, e0, n, s);
         });
-        if (e != hipSuccess) return fail(h, RANENV_E_HIP, "rollout launch %d: %s", i, hipGetErrorString(e));
+        if (e != hipSuccess) return fail(h, RANENV_E_HIP, "rollout, round %d of launches: %s", round, hipGetErrorString(e));
+        for (int k = 0; k < np; k++) pdone[(size_t)k] += pn[(size_t)k];
     }
     return RANENV_OK;
 }

@@ -50,16 +50,18 @@ def test_fused_rollouts_equal_one_launch_per_tti(monkeypatch, se_mode, parts):
 
 
 def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
-    """The profile counters: a rollout of 40 TTIs over 3 partitions is 3 x 4 launches of 10 TTIs (4 x 10 launch-TTIs per
-    partition); with RANENV_FUSE=1 it is 3 x 40 launches of one."""
+    """The profile counters: a rollout of 40 TTIs over 3 partitions is launches of up to 10 TTIs, the partitions' first ones
+    of different lengths; with RANENV_FUSE=1 it is 3 x 40 launches of one."""
     _need_gpu()
     monkeypatch.delenv("RANENV_FUSE", raising=False)          # (the default policy, whatever knob the suite runs under)
+    monkeypatch.delenv("RANENV_FUSE_FIRST", raising=False)
     a = _bench_like(96, False)
     a.env.reset(); a.env.set_partitions(3)
+    # first launches of 1 / 6 / 10 TTIs (partition 0 / 1 / 2), then 10s: 1+10+10+10+9, 6+10+10+10+4, 10+10+10+10
     a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
-    assert (pa["n_launches"], pa["n_ttis"]) == (12, 120)
-    a.env.profile_begin(); a.env.rollout(23); pa = a.env.profile_end()          # 5 + 5 + 5 + 5 + 3
-    assert (pa["n_launches"], pa["n_ttis"]) == (15, 69)
+    assert (pa["n_launches"], pa["n_ttis"]) == (14, 120)
+    a.env.profile_begin(); a.env.rollout(23); pa = a.env.profile_end()          # 1+5+5+5+5+2, 3+5+5+5+5, 5+5+5+5+3
+    assert (pa["n_launches"], pa["n_ttis"]) == (16, 69)
     a.env.profile_begin(); a.env.step(); pa = a.env.profile_end()
     assert (pa["n_launches"], pa["n_ttis"]) == (3, 3)
     a.env.close()
