@@ -319,9 +319,6 @@ DEVFN RowPlan make_row_plan(int n)
 #define RANENV_SE_DEPTH 2          /* 8-row groups of the SE tile in flight per lane in the lean streaming kernel (step / reset at row
                                       widths 8 and 10: 96 VGPRs without spills; the dense-mask and 16-wide builds keep 1) */
 #endif
-#ifndef RANENV_SE_RING
-#define RANENV_SE_RING 0           /* > 0: the lean streaming kernel keeps its SE queue in LDS, this many 8-row groups per wave */
-#endif
 #ifndef RANENV_DEFER_STATE
 #define RANENV_DEFER_STATE 2   /* the part of the UE state the allocation does not need is requested 0: at kernel entry, 1: before
                                   the queue's last turn, 2: after the stream (default: ~20 registers fewer while the tile
@@ -378,7 +375,8 @@ struct SeStream {
         for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
     // the queue as row_sums sees it: slot d's eight values (`after` = groups requested behind it: unused here, the
-    // compiler counts its own loads), and the request that refills the slot
+    // compiler counts its own loads; a queue kept in LDS by buffer_load ... lds with hand-written waits was built on this
+    // interface, measured and dropped, profiles/r03_ab_log.txt), and the request that refills the slot
     static constexpr int NSLOT = SE_NQ;
     DEVFN void take(int d, float (&x)[8], int) {
 #pragma unroll
@@ -387,68 +385,6 @@ struct SeStream {
     DEVFN void refill(int d, int r0) { load(q[d], r0); }
 };
 
-// The same queue in LDS instead of registers (-DRANENV_SE_RING=<groups>): every wave owns NG x 8 rows of 64 floats in the
-// workgroup's dynamic LDS and requests its rows with buffer_load ... lds (the data goes from the memory pipeline straight
-// into LDS, no VGPR holds it while in flight), so the depth of the queue costs LDS, not the registers that set the
-// occupancy.  The compiler knows nothing of these loads: the waits are written here.  vmcnt counts every vector memory
-// operation of the wave and loads retire in order, so "at most 8 x after outstanding" means slot d's eight rows have
-// landed whatever else the compiler has in flight (its own operations can only make the wait longer).
-extern __shared__ __attribute__((aligned(16))) float ranenv_dyn_lds[];
-template <int NG>
-struct SeRing {
-    typedef int rsrc4 __attribute__((ext_vector_type(4)));
-    rsrc4 rsrc;
-    int voff, row_bytes, last_row;
-    unsigned m0_base;              // LDS byte offset of this wave's ring (wave-uniform)
-    const float *rd;               // this lane's column of the ring
-    static constexpr int NSLOT = NG;
-    DEVFN void refill(int d, int r0)
-    {
-        int soff = r0 * row_bytes;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's previous rows were read out
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int so = soff < last_row ? soff : last_row;
-            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                         :: "s"(m0_base + (unsigned)((d * 8 + j) * 256)), "v"(voff), "s"(rsrc), "s"(so) : "memory");
-            soff += row_bytes;
-        }
-    }
-    DEVFN void take(int d, float (&x)[8], int after)
-    {
-        if (after <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (after == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (after == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (after == 4) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else if (after == 5) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = rd[(d * 8 + j) * 64];
-    }
-    DEVFN void init(const float *tile, int U, int u, int R)
-    {
-        static_assert(NG >= 1 && NG <= 7, "vmcnt is a 6-bit counter");
-        // the descriptor's four words by hand (what __builtin_amdgcn_make_buffer_rsrc packs: base, stride 0, bytes, flags)
-        const unsigned long long a = (unsigned long long)tile;
-        rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        rsrc.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
-        rsrc.z = __builtin_amdgcn_readfirstlane(U * R * 4);
-        rsrc.w = 0x00020000;
-        voff = u * 4; row_bytes = U * 4; last_row = (R - 1) * U * 4;
-        const int wave = threadIdx.x >> 6;
-        typedef __attribute__((address_space(3))) float *lds_ptr_t;
-        const unsigned base = (unsigned)(size_t)(lds_ptr_t)ranenv_dyn_lds;
-        m0_base = __builtin_amdgcn_readfirstlane(base + (unsigned)(wave * NG * 8 * 256));
-        rd = ranenv_dyn_lds + wave * NG * 8 * 64 + (threadIdx.x & 63);
-#pragma unroll
-        for (int d = 0; d < NG; d++) if (d * 8 < R) refill(d, d * 8);
-    }
-};
-template <int NQ> struct SeSource { typedef SeStream<NQ> type; };
-#define SE_RING_CASE(n) template <> struct SeSource<-n> { typedef SeRing<n> type; };
-SE_RING_CASE(1) SE_RING_CASE(2) SE_RING_CASE(3) SE_RING_CASE(4) SE_RING_CASE(5) SE_RING_CASE(6)
-#undef SE_RING_CASE
 
 // Sums of one row: `full` over all R RBs, `part` over the RBs selected by in(r).
 // Accumulators start at 0.0 instead of being initialised with the leaf's first group: 0.0 + x == x
@@ -748,8 +684,8 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
     if (tid < WAVE) {            // the other waves go straight to the barrier below
         const int s1 = tid;
         const bool ok1 = tid < GRP && s1 < S;
-        int active = 0, nues1 = 0, bsize = 1, msg = 1, sorted = 0;
-        if (ok1) { active = sh.si[s1][0]; nues1 = sh.si[s1][2]; bsize = sh.si[s1][3]; msg = sh.si[s1][5]; sorted = sh.si[s1][7]; }
+        int active = 0, nues1 = 0, sorted = 0;
+        if (ok1) { active = sh.si[s1][0]; nues1 = sh.si[s1][2]; sorted = sh.si[s1][7]; }
         double score = -1.0;
         if (mapf) {
             // backlog and sent Mbit of every slice (mapf.py:63-90): the two rows side by side, lanes 0..15 the occupancy row and
@@ -1001,7 +937,6 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
 #undef TBL
     const bool act = tid < U && !(compact && slc < 0);
     if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;     // (wave 0 stays: it runs the slice roles)
-    const size_t su = (size_t)e * U + u;
     const size_t er4 = (size_t)e * U * 4, er8 = (size_t)e * U * 8;      // this env's row of a per-UE array of 4- / 8-byte elements
     const unsigned u4 = (unsigned)u * 4u, u8 = (unsigned)u * 8u;
 #define UE4(f) row_at(ST_##f(p), er4, u4)
@@ -1062,7 +997,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
     }
     const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
-    typename SeSource<GATHER ? 1 : NQ>::type se1;
+    SeStream<GATHER ? 1 : NQ> se1;
     if (!GATHER) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables
@@ -1577,7 +1512,7 @@ DEVFN void step_loop(const KP &p)
 template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
-    step_loop<MODE, RANENV_SE_RING ? -RANENV_SE_RING : ((MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH), false, NP>(p);
+    step_loop<MODE, (MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP>(p);
 }
 template <int MODE, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
@@ -1670,15 +1605,14 @@ __global__ void __launch_bounds__(CORE_NT) ranenv_head_kernel(const KP p)
     const bool have = ue >= 0;
     const int gsh = (tid & 63) & ~(GRP - 1);
     const int n = __popc((unsigned)((__ballot(have) >> gsh) & 0xffffull));
-    int active = 0, has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0, usecase = 0;
+    int active = 0, has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
     int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
-    double pv[3] = {0.0, 0.0, 0.0}, priority = 0.0, traffic_tab = 0.0;
+    double pv[3] = {0.0, 0.0, 0.0}, traffic_tab = 0.0;
     if (in_grid) {
         const size_t row = (size_t)sc * S + s;
         const int32_t *si = TB_slice_i32(p) + row * 8;
         active = si[0]; has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
-        usecase = TB_slice_usecase(p)[row];
-        priority = TB_slice_f64(p)[row * 2 + 0]; traffic_tab = TB_slice_f64(p)[row * 2 + 1];
+        traffic_tab = TB_slice_f64(p)[row * 2 + 1];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             pm[k] = TB_param_i32(p)[(row * 3 + k) * 2 + 0];
@@ -2039,7 +1973,6 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
 template <int MODE, int NP>
 void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
 {
-    const unsigned ring_bytes = (unsigned)(RANENV_SE_RING * 8 * 256) * ((block.x + 63u) / 64u);     // the SE queue in LDS, per wave
     if (gather) {
         if constexpr (MODE != MODE_DENSE) {
             if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
@@ -2047,10 +1980,10 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
         }
     } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
         if (h->small_batch) hipExtLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
-        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, ring_bytes, stream, ev0, ev1, 0, kp);
+        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
     } else {
         if (h->small_batch) hipLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, kp);
-        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, ring_bytes, stream, kp);
+        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, kp);
     }
 }
 

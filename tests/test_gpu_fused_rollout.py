@@ -32,6 +32,7 @@ def test_fused_rollouts_equal_one_launch_per_tti(monkeypatch, se_mode, parts):
     """BASELINE configs[2]'s shape, 512 envs: rollouts of 1, 2, 7, 23 and 45 TTIs (launches of up to 1, 1, 1, 5 and 10
     TTIs, the last one of a rollout shorter) against the same rollouts with RANENV_FUSE=1."""
     _need_gpu()
+    monkeypatch.delenv("RANENV_FUSE", raising=False)          # (`a` runs the default policy whatever knob the suite runs under)
     a = _bench_like(512, se_mode == "gather")
     monkeypatch.setenv("RANENV_FUSE", "1")
     b = _bench_like(512, se_mode == "gather")
@@ -81,6 +82,7 @@ def test_fused_rollouts_across_device_autoresets(monkeypatch, se_mode, staggered
     the new episodes; with per-env episode lengths between 5 and 13 some episode ends almost every TTI and the launches
     shrink accordingly.  Same state, observations, episode numbers and per-episode metric sums as one launch per TTI."""
     _need_gpu()
+    monkeypatch.delenv("RANENV_FUSE", raising=False)
     envs = []
     for fuse in (None, "1"):
         if fuse:
@@ -120,6 +122,7 @@ def test_fused_rollout_with_the_traffic_drawn_on_the_device(monkeypatch):
     same TTIs draw one launch at a time."""
     _need_gpu()
     from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    monkeypatch.delenv("RANENV_FUSE", raising=False)
     envs = []
     for fuse in (None, "1"):
         if fuse:
