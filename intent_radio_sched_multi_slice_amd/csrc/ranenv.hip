@@ -1483,7 +1483,7 @@ DEVFN void step_loop(const KP &p)
         // Every TTI reads the kernel's arguments in place, through a pointer the optimiser cannot see through: nothing
         // derived from them is hoisted out of the loop and carried (= spilled) across a whole TTI.
         typedef const __attribute__((address_space(4))) KP *kp_const_t;
-        const int n = p.n_tti;
+        const int n = p.n_tti < 1 ? 1 : p.n_tti;      // (a launch steps at least once whatever the host left in the field)
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
