@@ -7,7 +7,7 @@ from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
 B = int(os.environ.get("KPROBE_BATCH", "4096"))
 wl, _ = make_bench_workload(2, torch.device("cuda", 0), batch=B)
 env = wl.env
-env.set_partitions(3); env.reset(); env.rollout(30); torch.cuda.synchronize()
+env.set_partitions(int(os.environ.get("KPROBE_PARTS", "3"))); env.reset(); env.rollout(30); torch.cuda.synchronize()
 for K in (20, 200):
     ts = []
     for _ in range(24 if K == 20 else 6):
