@@ -2078,12 +2078,17 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
         if (h->cfg.flags & RANENV_F_SYNC_CHECK) return hipStreamSynchronize(stream);
         return hipSuccess;
     }
+    // (nothing pending on the caller's stream = nothing for the partitions to wait for: no event round trip between the queues)
+    if (join_in && hipStreamQuery(stream) == hipSuccess) join_in = false;
     if (join_in) {
         le = hipEventRecord(h->ev_in, stream);
         if (le != hipSuccess) return le;
     }
     // partition 0 runs on the caller's stream itself (a process has few hardware queues -- 4 by default -- and streams
-    // beyond them share one, i.e. run one after the other), partitions 1.. on the handle's streams
+    // beyond them share one, i.e. run one after the other) and is enqueued first: it waits for no event, so the GPU has
+    // work ~10 us after the call instead of after the other partitions' event waits; partitions 1.. on the handle's streams
+    le = body(h->part_lo[0], h->part_lo[1] - h->part_lo[0], stream);
+    if (le != hipSuccess) return le;
     for (int k = 1; k < h->n_parts; k++) {
         hipStream_t ps = h->part_stream[k];
         if (join_in) { le = hipStreamWaitEvent(ps, h->ev_in, 0); if (le != hipSuccess) return le; }
@@ -2091,8 +2096,6 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
         if (le != hipSuccess) return le;
         if (join_out) { le = hipEventRecord(h->part_done[k], ps); if (le != hipSuccess) return le; }
     }
-    le = body(h->part_lo[0], h->part_lo[1] - h->part_lo[0], stream);
-    if (le != hipSuccess) return le;
     if (join_out)
         for (int k = 1; k < h->n_parts; k++) { le = hipStreamWaitEvent(stream, h->part_done[k], 0); if (le != hipSuccess) return le; }
     if (h->cfg.flags & RANENV_F_SYNC_CHECK) {
@@ -2698,12 +2701,12 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
             const int left = n_steps - pdone[(size_t)k];
             int n_tti = left < fuse ? left : fuse;
             if (round == 0 && fuse > 1 && np > 1) {
-                // The partitions' first launches differ in length, the one enqueued last (partition 0, on the caller's
-                // stream) starting with a single TTI: it is the one whose workgroups find the slots taken (4096 envs want
+                // The partitions' first launches differ in length, the one enqueued last (the highest partition)
+                // starting with a single TTI: it is the one whose workgroups find the slots taken (4096 envs want
                 // 3738), and after one short launch its late starters are through instead of holding its chain up for a
                 // whole long one; from then on the partitions' launch boundaries no longer coincide (K = 20: -2 % streaming,
                 // -4 % gather; profiles/r03_ab_log.txt).  RANENV_FUSE_FIRST=a,b,c overrides (0 = the common length).
-                int first = k == 0 ? 1 : ((k & 1) ? (3 * fuse + 4) / 5 : fuse);
+                int first = k == np - 1 ? 1 : ((k & 1) ? (3 * fuse + 4) / 5 : fuse);
                 if (!h->fuse_first.empty()) first = (size_t)k < h->fuse_first.size() ? h->fuse_first[(size_t)k] : 0;
                 if (first > 0 && first < n_tti) n_tti = first;
             }
