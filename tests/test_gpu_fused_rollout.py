@@ -58,10 +58,10 @@ def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
     monkeypatch.delenv("RANENV_FUSE_FIRST", raising=False)
     a = _bench_like(96, False)
     a.env.reset(); a.env.set_partitions(3)
-    # first launches of 1 / 6 / 10 TTIs (partition 0 / 1 / 2), then 10s: 1+10+10+10+9, 6+10+10+10+4, 10+10+10+10
+    # first launches of 10 / 6 / 1 TTIs (partition 0 / 1 / 2), then 10s: 10+10+10+10, 6+10+10+10+4, 1+10+10+10+9
     a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
     assert (pa["n_launches"], pa["n_ttis"]) == (14, 120)
-    a.env.profile_begin(); a.env.rollout(23); pa = a.env.profile_end()          # 1+5+5+5+5+2, 3+5+5+5+5, 5+5+5+5+3
+    a.env.profile_begin(); a.env.rollout(23); pa = a.env.profile_end()          # 5+5+5+5+3, 3+5+5+5+5, 1+5+5+5+5+2
     assert (pa["n_launches"], pa["n_ttis"]) == (16, 69)
     a.env.profile_begin(); a.env.step(); pa = a.env.profile_end()
     assert (pa["n_launches"], pa["n_ttis"]) == (3, 3)
