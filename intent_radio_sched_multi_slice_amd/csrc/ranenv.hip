@@ -757,7 +757,10 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
                 int rank = 0;
 #pragma unroll
                 for (int j = 0; j < NP; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
-                extra = adj < m_nz ? (rank < adj ? 1 : 0) : (adj / m_nz + (rank < adj % m_nz ? 1 : 0));
+                // the floors leave fewer than m_nz units over unless rounding interferes: the integer division (~50 vector
+                // instructions with its remainder) only where some lane needs it
+                extra = rank < adj ? 1 : 0;
+                if (__builtin_amdgcn_ballot_w64(adj >= m_nz) != 0 && adj >= m_nz) extra = adj / m_nz + (rank < adj % m_nz ? 1 : 0);
             }
             const int mine = (my_prop + extra) * p.G;                                    // ib_sched.py:268
             const int incl = row16_scan(mine);
@@ -834,7 +837,9 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             int rank = 0;
 #pragma unroll
             for (int k = 0; k < NP; k++) { const double xk = r2[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
-            count += adj < m_v ? (rank < adj ? 1 : 0) : (adj / m_v + (rank < adj % m_v ? 1 : 0));
+            int more = rank < adj ? 1 : 0;
+            if (__builtin_amdgcn_ballot_w64(adj >= m_v) != 0 && adj >= m_v) more = adj / m_v + (rank < adj % m_v ? 1 : 0);      // (as above)
+            count += more;
         }
     } else {
         // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
