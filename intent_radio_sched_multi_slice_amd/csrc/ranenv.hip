@@ -337,6 +337,9 @@ DEVFN RowPlan make_row_plan(int n)
 #ifndef RANENV_METRICS
 #define RANENV_METRICS 1           /* 0 compiles the episode-metric sums out (A/B of their cost only) */
 #endif
+#ifndef RANENV_WARM_ENTRY
+#define RANENV_WARM_ENTRY 1        /* 0: every TTI of a multi-TTI launch enters like the first (loads everything back) */
+#endif
 #ifndef RANENV_LATE_BUILT
 #define RANENV_LATE_BUILT 1        /* 0 compiles the allocation-ahead path out */
 #endif
@@ -868,9 +871,21 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
 // The kernel body, instantiated per build (see the kernels behind it): NQ = groups of 8 SE loads in flight per lane;
 // GATHER = the SE gather mode (the tile's per-UE mean from the sidecar, the masked sum by gather_part from the UE-major
 // copy; p.se_pool / p.se_stride then describe that copy) instead of streaming the whole RB-major tile.
+// What a launch that steps several TTIs (step_loop) hands from one TTI to the next in registers instead of storing it and
+// loading it back: the env's counters (uniform), the lane's table row and the three values of its UE's state that the
+// allocation reads.  Every dependent load the entry does not make is ~1.5 us of a workgroup's life under load -- hit or miss:
+// it queues behind the other workgroups' SE loads.
+struct StepCarry {
+    ranenv_episode ep;
+    int t, hlen, npush, se_pos, trf_pos, ptot, cmark, episode_no;
+    int u, slc, ue_pos, pkt_size, max_pkts, max_age, total;
+    long long win_sent;
+    double sem_prev;
+};
+
 template <int MODE, int NQ, bool GATHER, int NP, typename P>
-DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
-{
+DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm)   // warm: `cy` holds what the previous TTI of this launch left
+{                                     // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     __shared__ SharedCore<NP> sh;
     auto &xr = sh.xr;
@@ -900,17 +915,23 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
 #else
 #define COLD(f) (p.f)
 #endif
-    ranenv_episode ep = p.episodes[e];
-    ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
-    ep.se_len = uni(ep.se_len); ep.trf_len = uni(ep.trf_len);
-    ep.se_base = uni64(ep.se_base); ep.trf_base = uni64(ep.trf_base);
+    ranenv_episode ep;
+    int t, hlen, npush, se_pos, trf_pos;
+    if (!warm) {
+        ep = p.episodes[e];
+        ep.scenario = uni(ep.scenario); ep.se_offset = uni(ep.se_offset); ep.trf_offset = uni(ep.trf_offset);
+        ep.se_len = uni(ep.se_len); ep.trf_len = uni(ep.trf_len);
+        ep.se_base = uni64(ep.se_base); ep.trf_base = uni64(ep.trf_base);
+        t = (MODE == MODE_RESET) ? 0 : uni(ST_step_no(p)[e]);
+        hlen = uni(ST_hist_len(p)[e]);
+        npush = uni(ST_n_push(p)[e]);                    // kept in [0, D)
+        // a position persisted under an older, longer trace must not index past the current one
+        se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(ST_se_pos(p)[e]);
+        trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(ST_trf_pos(p)[e]);
+    } else {
+        ep = cy.ep; t = cy.t; hlen = cy.hlen; npush = cy.npush; se_pos = cy.se_pos; trf_pos = cy.trf_pos;
+    }
     const int sc = ep.scenario;
-    const int t = (MODE == MODE_RESET) ? 0 : uni(ST_step_no(p)[e]);
-    int hlen = uni(ST_hist_len(p)[e]);
-    const int npush = uni(ST_n_push(p)[e]);                    // kept in [0, D)
-    // a position persisted under an older, longer trace must not index past the current one
-    int se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(ST_se_pos(p)[e]);
-    int trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(ST_trf_pos(p)[e]);
     se_pos = se_pos < ep.se_len ? se_pos : 0;
     trf_pos = trf_pos < ep.trf_len ? trf_pos : 0;
     const int hlen_old = hlen;                                // window length the allocation sees
@@ -936,24 +957,35 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
     const size_t tb_row = ((size_t)sc * U + (compact ? (size_t)0 : (size_t)6 * (size_t)p.NSU)) * 4;
     const unsigned lane4 = (unsigned)lane * 4u;
 #define TBL(f) row_at(TB_##f(p), tb_row, lane4)
-    const int u = compact ? TBL(lane_ue) : lane;      // (set 1 is the identity: no load, and the state loads need not wait for it)
-    const int slc = TBL(ue_slice), ue_pos = TBL(ue_pos);
-    const int pkt_size = TBL(ue_pkt_size), max_pkts = TBL(ue_max_pkts), max_age = TBL(ue_max_age);
+    int u, slc, ue_pos, pkt_size, max_pkts, max_age;
+    if (!warm) {
+        u = compact ? TBL(lane_ue) : lane;      // (set 1 is the identity: no load, and the state loads need not wait for it)
+        slc = TBL(ue_slice); ue_pos = TBL(ue_pos);
+        pkt_size = TBL(ue_pkt_size); max_pkts = TBL(ue_max_pkts); max_age = TBL(ue_max_age);
+    } else {
+        u = cy.u; slc = cy.slc; ue_pos = cy.ue_pos; pkt_size = cy.pkt_size; max_pkts = cy.max_pkts; max_age = cy.max_age;
+        // (opaque, like the thread id above: what is derived from them -- LDS and row addresses -- is formed anew every TTI)
+        asm volatile("" : "+v"(u), "+v"(slc), "+v"(ue_pos));
+    }
 #undef TBL
     const bool act = tid < U && !(compact && slc < 0);
-    if (compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;     // (wave 0 stays: it runs the slice roles)
+    if (!warm && compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;     // (wave 0 stays: it runs the slice roles)
     const size_t er4 = (size_t)e * U * 4, er8 = (size_t)e * U * 8;      // this env's row of a per-UE array of 4- / 8-byte elements
     const unsigned u4 = (unsigned)u * 4u, u8 = (unsigned)u * 8u;
 #define UE4(f) row_at(ST_##f(p), er4, u4)
 #define UE8(f) row_at(ST_##f(p), er8, u8)
-    const int ptot = uni(ST_push_total(p)[e]);      // window pushes of this env so far (wraps; only differences are used)
-    const int cmark = uni(ST_clear_mark(p)[e]);     // index of the first push behind the last clearing of the window
+    // window pushes of this env so far (wraps; only differences are used); index of the first push behind the last clearing
+    const int ptot = warm ? cy.ptot : uni(ST_push_total(p)[e]);
+    const int cmark = warm ? cy.cmark : uni(ST_clear_mark(p)[e]);
     int lastp = ptot;                               // index behind this UE's last push
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
     double sem_prev = 0.0;
-    if (MODE != MODE_RESET) total = UE4(queue_pkts);
-    if (!clear_hist) win_sent = UE8(win_sent);
+    if (warm) { total = cy.total; win_sent = cy.win_sent; sem_prev = cy.sem_prev; }
+    else {
+        if (MODE != MODE_RESET) total = UE4(queue_pkts);
+        if (!clear_hist) win_sent = UE8(win_sent);
+    }
     // (this push's slots of the two rings: the addresses are formed where they are used, not carried through the step)
     auto ring_s = [&]() { return &row_at(ST_ring_sent(p), ((size_t)e * D + npush) * U * 4, u4); };
     auto ring_d = [&]() { return &row_at(ST_ring_drop(p), ((size_t)e * D + npush) * U * 4, u4); };
@@ -974,12 +1006,12 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
 #if !RANENV_DEFER_STATE
     rest_of_state();
 #endif
-    if (MODE == MODE_STEP) sem_prev = UE8(se_mean);
+    if (MODE == MODE_STEP && !warm) sem_prev = UE8(se_mean);
     double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
     if (GATHER) sem_tile = row_at(p.se_mean_pool, (size_t)tile_no * U * 8, u8);
     // the scenario's slice tables, parked in LDS below by wave 0 (the other waves may have left): up to two words per lane
     int st_si0 = 0, st_si1 = 0, st_pi0 = 0, st_pi1 = 0; double st_pf = 0.0, st_sf = 0.0;
-    if (tid < WAVE) {
+    if (tid < WAVE && !warm) {
         const unsigned t4 = (unsigned)tid * 4u, t8 = (unsigned)tid * 8u;
         if (tid < S * 8) st_si0 = row_at(TB_slice_i32(p), (size_t)sc * S * 32, t4);
         if (tid + WAVE < S * 8) st_si1 = row_at(TB_slice_i32(p), (size_t)sc * S * 32, t4 + WAVE * 4u);
@@ -990,7 +1022,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
     }
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
-    if (RANENV_LATE_BUILT && MODE == MODE_STEP && p.scores == nullptr && p.late != 0) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
+    if (RANENV_LATE_BUILT && MODE == MODE_STEP && p.scores == nullptr && p.late != 0 && !warm) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
 #if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8    /* ablations: 8 = no allocation and no obs tail; 10 = allocation + tail only; 6 = entry + stream only (ranges from the stored allocation, sums written out); 7 = no allocation */
     if (MODE == MODE_STEP) pre = true;
 #endif
@@ -1000,13 +1032,15 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
         if (tid < S) row_at(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
 #endif
     }
-    const int episode_no = gen_traffic ? uni(ST_episode_no(p)[e]) : 0;
+    const int episode_no = warm ? cy.episode_no : (gen_traffic ? uni(ST_episode_no(p)[e]) : 0);
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
     SeStream<GATHER ? 1 : NQ> se1;
     if (!GATHER) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
-    // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables
-    if (tid < WAVE) {
+    // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables.
+    // A warm TTI finds both as it needs them: the tables are the scenario's, and every role writes a slice's rows at its
+    // members' positions only, so what lies beyond them is still the zeros of the launch's first TTI.
+    if (tid < WAVE && !warm) {
         for (int i = tid; i < S * 4 * NP; i += WAVE) {
             const int sl0 = i / (4 * NP), rem = i - sl0 * (4 * NP), k0 = rem / NP, j0 = rem - k0 * NP;
             sh.rows[sl0][k0 * NP + j0] = 0.0;
@@ -1019,7 +1053,7 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
         if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
         if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
     }
-    wg_sync();
+    if (!warm) wg_sync();            // (a warm TTI starts behind step_loop's barrier)
     RANENV_STAMP(1);
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
@@ -1472,6 +1506,13 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
     }
     if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
     RANENV_STAMP(8);
+    if (MODE == MODE_STEP) {         // for the next TTI of this launch, if there is one (what tid 0 has just stored, and this lane's own)
+        cy.ep = ep; cy.t = t + 1; cy.hlen = hlen_new; cy.npush = npush + 1 == D ? 0 : npush + 1;
+        cy.se_pos = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1; cy.trf_pos = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
+        cy.ptot = ptot + 1; cy.cmark = (ptot + 1 - cmark > 2 * D) ? ptot + 1 - 2 * D : cmark; cy.episode_no = episode_no;
+        cy.u = u; cy.slc = slc; cy.ue_pos = ue_pos; cy.pkt_size = pkt_size; cy.max_pkts = max_pkts; cy.max_age = max_age;
+        cy.total = total; cy.win_sent = win_sent; cy.sem_prev = act ? sem_new : sem_prev;
+    }
     return false;
 #undef UE4
 #undef UE8
@@ -1481,22 +1522,30 @@ DEVFN bool step_body(const P &p)      // -> true: this wave has left for good (n
 // steps its env again as soon as it is done, from the state it has just written (its own CU's L1 / L2 hold it), instead
 // of ending and being launched again.  Between TTIs: every store of the workgroup is out and visible to its other
 // waves (__syncthreads = wait for the wave's memory operations + barrier; the waves of a workgroup share their CU's L1).
-template <int MODE, int NQ, bool GATHER, int NP>
+template <int MODE, int NQ, bool GATHER, int NP, bool MANY>      // MANY: the build for launches of more than one TTI
 DEVFN void step_loop(const KP &p)
 {
     if constexpr (MODE == MODE_STEP) {
         // Every TTI reads the kernel's arguments in place, through a pointer the optimiser cannot see through: nothing
         // derived from them is hoisted out of the loop and carried (= spilled) across a whole TTI.
         typedef const __attribute__((address_space(4))) KP *kp_const_t;
-        const int n = p.n_tti < 1 ? 1 : p.n_tti;      // (a launch steps at least once whatever the host left in the field)
+        const int n = MANY ? (p.n_tti < 1 ? 1 : p.n_tti) : 1;      // (a launch steps at least once whatever the host left in the field)
+        StepCarry cy = {};
+        bool warm = false;
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
-            if (step_body<MODE, NQ, GATHER, NP>(*kc)) return;
-            if (k + 1 < n) __syncthreads();
+            if (step_body<MODE, NQ, GATHER, NP>(*kc, cy, warm)) return;
+            if (k + 1 < n) {
+                // The next TTI takes over in registers what it would otherwise load back (StepCarry) -- unless it has to look
+                // for an allocation made ahead (RANENV_LATE) -- and then only LDS has to be handed over between the waves.
+                warm = MANY && RANENV_WARM_ENTRY && kc->late == 0;
+                if (warm) wg_sync(); else __syncthreads();
+            }
         }
     } else {
-        step_body<MODE, NQ, GATHER, NP>(p);
+        StepCarry cy = {};
+        step_body<MODE, NQ, GATHER, NP>(p, cy, false);
     }
 }
 #undef COLD
@@ -1514,23 +1563,25 @@ DEVFN void step_loop(const KP &p)
 #else
 #define RANENV_CORE_ATTR
 #endif
-template <int MODE, int NP>
+// (MANY: a launch of several TTIs, ranenv_rollout only, runs a build of its own -- the one-TTI build stays free of the
+// warm entry's second path through the role, which costs it 1-2 %)
+template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
-    step_loop<MODE, (MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP>(p);
+    step_loop<MODE, (MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP, MANY>(p);
 }
-template <int MODE, int NP>
+template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
 {
-    step_loop<MODE, RANENV_SE_DEPTH_SMALL, false, NP>(p);
+    step_loop<MODE, RANENV_SE_DEPTH_SMALL, false, NP, MANY>(p);
 }
 // The SE gather build (ranenv_set_se_mode): no tile stream, so no queue registers; one build for every batch size.
 #ifndef RANENV_GATHER_WAVES_PER_EU
 #define RANENV_GATHER_WAVES_PER_EU 5
 #endif
-template <int MODE, int NP>
+template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_GATHER_WAVES_PER_EU, RANENV_GATHER_WAVES_PER_EU)))
-ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP>(p); }
+ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP, MANY>(p); }
 // Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
 
 // ---------------------------------------------------------------------------------------------
@@ -1975,21 +2026,29 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
 }
 
 // The build of the step kernel for this handle: SE gather or streaming (lean / small-batch), row width NP.
-template <int MODE, int NP>
-void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
+template <int MODE, int NP, bool MANY>
+void launch_kernels_of(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
 {
     if (gather) {
         if constexpr (MODE != MODE_DENSE) {
-            if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
-            else hipLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP>), grid, block, 0, stream, kp);
+            if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
+            else hipLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP, MANY>), grid, block, 0, stream, kp);
         }
     } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
-        if (h->small_batch) hipExtLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
-        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+        if (h->small_batch) hipExtLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
+        else hipExtLaunchKernelGGL((ranenv_core_kernel<MODE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
     } else {
-        if (h->small_batch) hipLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP>), grid, block, 0, stream, kp);
-        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP>), grid, block, 0, stream, kp);
+        if (h->small_batch) hipLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP, MANY>), grid, block, 0, stream, kp);
+        else hipLaunchKernelGGL((ranenv_core_kernel<MODE, NP, MANY>), grid, block, 0, stream, kp);
     }
+}
+template <int MODE, int NP>
+void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
+{
+    if constexpr (MODE == MODE_STEP) {
+        if (kp.n_tti > 1) { launch_kernels_of<MODE, NP, true>(h, kp, grid, block, stream, ev0, ev1, gather); return; }
+    }
+    launch_kernels_of<MODE, NP, false>(h, kp, grid, block, stream, ev0, ev1, gather);
 }
 
 // One launch of the step kernel for envs [e0, e0 + n) on `stream` (+ the head kernel when bound).
@@ -2230,7 +2289,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
             h->small_batch = (long long)cfg->batch <= 8ll * prop.multiProcessorCount;
         if (const char *sv = getenv("RANENV_SMALL_BATCH")) h->small_batch = atoi(sv) != 0;   // experiment knob
-        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP, 16>));
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP, 16, false>));
         if (e != hipSuccess) {
             ranenv_destroy(h);
             return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
