@@ -11,11 +11,12 @@ miniature: the inter-slice agent ("player_0") is a masked diagonal Gaussian over
 observations, the other range's TTI occupies the GPU.  Episode ends are handled on the device (enable_autoreset).
 
 This is an example of the API, not a tuned trainer: it prints env-steps/s with the policy in the loop and the mean
-inter-slice reward as training goes on.  Measured on one MI355X (B = 4096, gather mode): 6.6 M env-steps/s with one range,
-3.7 M with two -- the loop is bound by the HOST: an eager torch policy is ~15 small kernels per decision (~250 us of Python
-and launch time per range and TTI against ~45 us of env step), and every further range adds that much host work per TTI.
+inter-slice reward as training goes on.  Measured on one MI355X (B = 4096, gather mode): 3-7 M env-steps/s with one range
+(it depends on the box's host cores), about half of that with two -- the loop is bound by the HOST: an eager torch policy is
+~15 small kernels per decision (250-600 us of Python and launch time per range and TTI against ~45 us of env step), and every
+further range adds that much host work per TTI.
 Ranges pay off once the policy costs the host little (a fused or graph-captured forward): `bench.py`'s `pipelined_step`
-runs the same schedule with a one-kernel policy at 55 M env-steps/s.
+runs the same schedule with a one-kernel policy at 55 M env-steps/s (70 M in gather mode).
 """
 import argparse
 import os
