@@ -16,7 +16,7 @@ inter-slice reward as training goes on.  Measured on one MI355X (B = 4096, gathe
 ~15 small kernels per decision (250-600 us of Python and launch time per range and TTI against ~45 us of env step), and every
 further range adds that much host work per TTI.
 Ranges pay off once the policy costs the host little (a fused or graph-captured forward): `bench.py`'s `pipelined_step`
-runs the same schedule with a one-kernel policy at 55 M env-steps/s (70 M in gather mode).
+runs the same schedule with a one-kernel policy at 55 M env-steps/s (~80 M in gather mode, tools/pipeprobe.py).
 """
 import argparse
 import os
