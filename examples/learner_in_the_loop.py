@@ -66,9 +66,12 @@ def main():
     def act(k):
         """Scores of range k from its last observation, on the current (= the range's) stream; returns log-prob."""
         lo, hi = ranges[k]
-        obs = env.obs_inter[lo:hi]
-        mean, std = masked_gaussian_params(torch.tanh(policy(obs)), log_std.expand(hi - lo, S),
-                                           sorted_action_mask(mask_view[lo:hi]))
+        # CLONE what the autograd graph keeps: env.obs_inter and the mask are overwritten in place by the next TTI's kernel
+        # (no version counter sees a HIP kernel's stores), and backward() runs update_every TTIs later -- a saved zero-copy view
+        # would backpropagate every transition with the latest observation instead of its own.
+        obs = env.obs_inter[lo:hi].clone()
+        mask = mask_view[lo:hi].clone()
+        mean, std = masked_gaussian_params(torch.tanh(policy(obs)), log_std.expand(hi - lo, S), sorted_action_mask(mask))
         eps = torch.randn_like(mean)
         scores[lo:hi].copy_(torch.clamp(mean.detach() + std.detach() * eps, -1.0, 1.0))     # float32 in, float64 scores out
         return -(0.5 * eps * eps + torch.log(std)).sum(dim=1)      # log-density of the draw, up to a constant

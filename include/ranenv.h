@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 7
+#define RANENV_ABI_VERSION 8
 
 enum {
     RANENV_OK = 0,
@@ -359,6 +359,31 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *dev_obs_in
  * chains keeps the episode advance on the device and inside each chain.  All arrays are the whole-batch arrays. */
 int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done, float *dev_obs_inter, float *dev_obs_intra,
                           float *dev_term_obs_inter, float *dev_term_obs_intra, float *dev_term_obs_head, void *stream);
+
+/* Options: tuning and debug knobs of the launch schedule.  NONE of them changes a result -- every setting is covered by the
+ * bit-for-bit tests -- they select a build of the step kernel or the way launches are issued.  They are set per handle by
+ * ranenv_set_option(h, key, value); ranenv_create presets them from the process environment, ONE variable per key,
+ * RANENV_<KEY IN CAPITALS> (read in one place, apply_env_options in csrc/ranenv.hip; the GPU test suite and the A/B tools under
+ * tools/ run whole passes that way).  Nothing else in the library reads the environment.
+ *
+ *   key            env variable         default   meaning
+ *   "compact"      RANENV_COMPACT       1         0: never step compactly (see "Compact steps" above), always full width
+ *   "fuse"         RANENV_FUSE          0         TTIs one launch of ranenv_rollout takes its envs through: 0 = chosen per
+ *                                                 rollout (a quarter of n_steps, at most 10), n = at most n, 1 = one TTI per launch
+ *   "fuse_first0"  RANENV_FUSE_FIRST    0         length of partition 0's FIRST launch of a rollout (0 = the staggered default:
+ *   ... "fuse_first9"  (= a,b,c list)             the partition enqueued last starts with one TTI); keys 0..9 = partitions 0..9
+ *   "late"         RANENV_LATE          0         1 / 2: a hashed half of / all envs under a device policy make the NEXT TTI's
+ *                                                 allocation at the end of a step (the default while a launch was one TTI)
+ *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
+ *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
+ *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one
+ *   "persist"      RANENV_PERSIST       0         see ranenv_rollout
+ *
+ * Python host layer only (batched_env.py, not this library): RANENV_SE_MODE=gather makes BatchedRanEnv.bind_se_pool switch
+ * to the SE gather mode, RANENV_LIB=<path> loads another build of this library.
+ * ranenv_get_option reads a key back.  Unknown keys and unusable values return RANENV_E_INVALID. */
+int ranenv_set_option(ranenv_handle h, const char *key, int64_t value);
+int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value);
 
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -421,7 +421,9 @@ class BatchedRanEnv:
 
     def step_wait(self, k: int):
         """Order the caller's current stream behind range ``k``'s last ``step_async`` (no host sync) and return views of
-        that range's rows: ({"obs_inter", "obs_intra"}, reward, done)."""
+        that range's rows: ({"obs_inter", "obs_intra"}, reward, done).  They are zero-copy views of buffers the range's NEXT
+        step_async overwrites in place from a HIP kernel (autograd's version counters do not see it): clone whatever a
+        graph or a replay buffer keeps beyond that call."""
         st = self._lib.ranenv_wait_part(self._h, k, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if st != 0:
             self._check(st, "ranenv_wait_part")
@@ -585,6 +587,16 @@ class BatchedRanEnv:
             raise RanEnvError(f"an env finished only {int(done.min())} of {n_episodes} episodes: per-env max_steps longer than assumed")
         log = m["episode_log"][:, :n_episodes].cpu().numpy()
         return {name: log[:, :, k].copy() for k, name in enumerate(self.METRIC_NAMES)}
+
+    def set_option(self, key: str, value: int) -> None:
+        """A tuning / debug knob of the launch schedule (include/ranenv.h, "Options": compact, fuse, fuse_first0..9, late,
+        row_width, small_batch, persist).  None of them changes a result."""
+        self._check(self._lib.ranenv_set_option(self._h, key.encode(), int(value)), f"ranenv_set_option({key})")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        self._check(self._lib.ranenv_get_option(self._h, key.encode(), C.byref(v)), f"ranenv_get_option({key})")
+        return int(v.value)
 
     def launch_info(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1197,6 +1198,15 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm)   // warm: `cy`
                 *qs = 0; *qd = 0;
             }
         }
+        // A clearing reset also empties the UE's ring: the catch-up above subtracts what a slot holds on the assumption that
+        // it belongs to the current window era, and a UE that pushed fewer than D times since the clear and then sat out
+        // more than D pushes would otherwise give up values of the era before (a reset steps every UE: full width).
+        if (MODE == MODE_RESET && clear_hist) {
+            for (int k = 0; k < D; k++) {
+                row_at(ST_ring_sent(p), ((size_t)e * D + k) * U * 4, u4) = 0;
+                row_at(ST_ring_drop(p), ((size_t)e * D + k) * U * 4, u4) = 0;
+            }
+        }
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
         win_sent += sent - old_s; win_drop += dropped - old_d;
         *ring_s() = (int32_t)sent; *ring_d() = (int32_t)dropped;
@@ -1916,6 +1926,8 @@ struct ranenv {
     int se_mode = RANENV_SE_STREAM;
     double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
     // compact steps (KP::compact): allowed while UEs outside every slice provably receive no traffic
+    bool persist = false;          // ranenv_rollout as one persistent work-queue launch per workgroup class (option "persist")
+    int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
     int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
     std::vector<int> fuse_first;   // override of the length of partition k's first launch of a rollout (RANENV_FUSE_FIRST=a,b,c)
     long long prof_ttis = 0;       // TTIs covered by the launches timed since ranenv_profile_begin
@@ -2143,7 +2155,12 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
         return hipSuccess;
     }
     // (nothing pending on the caller's stream = nothing for the partitions to wait for: no event round trip between the queues)
-    if (join_in && hipStreamQuery(stream) == hipSuccess) join_in = false;
+    // (hipStreamQuery is illegal on a capturing stream: a caller that graph-captures its step keeps the event)
+    if (join_in) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs == hipStreamCaptureStatusNone && hipStreamQuery(stream) == hipSuccess) join_in = false;
+    }
     if (join_in) {
         le = hipEventRecord(h->ev_in, stream);
         if (le != hipSuccess) return le;
@@ -2207,6 +2224,52 @@ AdvanceArgs advance_args(ranenv_handle h, const uint8_t *dev_done, float *obs_in
     return a;
 }
 
+// Tuning / debug options (include/ranenv.h, "Options"): ONE setter behind ranenv_set_option, and ONE place where the
+// process environment is read (ranenv_create -> apply_env_options: RANENV_<KEY IN CAPITALS>=value presets the same
+// options for handles created afterwards; the test suite and the A/B tools run whole passes under them).
+// None of them changes a result: they select a launch schedule or a build of the step kernel.
+int set_option(ranenv_handle h, const std::string &k, long long v)
+{
+    if (k == "compact") { h->compact_enabled = v != 0; return RANENV_OK; }
+    if (k == "fuse") { h->fuse = v < 0 ? 0 : (v > 64 ? 64 : (int)v); return RANENV_OK; }
+    if (k == "late") { h->kp.late = v < 0 ? 0 : (v > 2 ? 2 : (int)v); h->alloc_gen++; return RANENV_OK; }
+    if (k == "row_width") {
+        const int m = h->cfg.n_slices > h->cfg.max_ues_slice ? h->cfg.n_slices : h->cfg.max_ues_slice;
+        if (!((v == 8 || v == 10 || v == 16) && v >= m))
+            return fail(h, RANENV_E_INVALID, "row_width must be 8, 10 or 16 and >= max(S, Us) = %d", m);
+        h->np = (int)v;
+        return RANENV_OK;
+    }
+    if (k == "small_batch") { h->small_batch = v != 0; return RANENV_OK; }
+    if (k == "persist") { h->persist = v != 0; return RANENV_OK; }
+    if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
+    if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
+        const size_t i = (size_t)(k[10] - '0');
+        if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
+        h->fuse_first[i] = v < 0 ? 0 : (int)v;
+        return RANENV_OK;
+    }
+    return fail(h, RANENV_E_INVALID, "unknown option '%s'", k.c_str());
+}
+
+void apply_env_options(ranenv_handle h)
+{
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk"};
+    for (const char *key : keys) {
+        std::string name = "RANENV_";
+        for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
+        if (const char *v = getenv(name.c_str())) (void)set_option(h, key, atoll(v));      // (an unusable value is ignored)
+    }
+    if (const char *ff = getenv("RANENV_FUSE_FIRST")) {      // a list: a,b,c = partitions 0, 1, 2
+        int i = 0;
+        for (const char *c = ff; *c && i < 10; i++) {
+            (void)set_option(h, std::string("fuse_first") + (char)('0' + i), atoll(c));
+            while (*c && *c != ',') c++;
+            if (*c) c++;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -2253,10 +2316,6 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.L = (int)L; kp.max_steps = cfg->max_steps; kp.flags = cfg->flags;
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
     kp.late = RANENV_LATE_DEFAULT;
-    if (const char *cv = getenv("RANENV_COMPACT")) h->compact_enabled = atoi(cv) != 0;                     // experiment knob
-    if (const char *ff = getenv("RANENV_FUSE_FIRST")) { for (const char *c = ff; *c;) { h->fuse_first.push_back(atoi(c)); while (*c && *c != ',') c++; if (*c) c++; } }
-    if (const char *fv = getenv("RANENV_FUSE")) h->fuse = atoi(fv) < 0 ? 0 : (atoi(fv) > 64 ? 64 : atoi(fv));   // experiment knob
-    if (const char *lv = getenv("RANENV_LATE")) kp.late = atoi(lv) < 0 ? 0 : (atoi(lv) > 2 ? 2 : atoi(lv));   // experiment knob
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
     kp.norm_traffic = cfg->norm_traffic; kp.norm_ues = cfg->norm_ues; kp.norm_se = cfg->norm_se;
     int rc = RANENV_OK;
@@ -2281,21 +2340,43 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     {
         const int m = S > Us ? S : Us;
         h->np = m <= 8 ? 8 : (m <= 10 ? 10 : 16);
-        if (const char *nv = getenv("RANENV_ROW_WIDTH")) { const int v = atoi(nv); if ((v == 8 || v == 10 || v == 16) && v >= m) h->np = v; }   // experiment knob
     }
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
             h->small_batch = (long long)cfg->batch <= 8ll * prop.multiProcessorCount;
-        if (const char *sv = getenv("RANENV_SMALL_BATCH")) h->small_batch = atoi(sv) != 0;   // experiment knob
         e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP, 16, false>));
         if (e != hipSuccess) {
             ranenv_destroy(h);
             return fail(nullptr, RANENV_E_HIP, "no usable gfx950 kernel image (hipFuncGetAttributes: %s)", hipGetErrorString(e));
         }
     }
+    apply_env_options(h);
     *out = h;
+    return RANENV_OK;
+}
+
+int ranenv_set_option(ranenv_handle h, const char *key, int64_t value)
+{
+    if (!h || !key) return fail(h, RANENV_E_INVALID, "null argument");
+    return set_option(h, key, (long long)value);
+}
+
+int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
+{
+    if (!h || !key || !value) return fail(h, RANENV_E_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "compact") *value = h->compact_enabled ? 1 : 0;
+    else if (k == "fuse") *value = h->fuse;
+    else if (k == "late") *value = h->kp.late;
+    else if (k == "row_width") *value = h->np;
+    else if (k == "small_batch") *value = h->small_batch ? 1 : 0;
+    else if (k == "persist") *value = h->persist ? 1 : 0;
+    else if (k == "persist_chunk") *value = h->persist_chunk;
+    else if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9')
+        *value = (size_t)(k[10] - '0') < h->fuse_first.size() ? h->fuse_first[(size_t)(k[10] - '0')] : 0;
+    else return fail(h, RANENV_E_INVALID, "unknown option '%s'", key);
     return RANENV_OK;
 }
 
@@ -2643,7 +2724,9 @@ int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream_)
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "SE sidecar launch: %s", hipGetErrorString(e));
-    if (h->cfg.flags & RANENV_F_SYNC_CHECK) HIP_TRY(h, hipStreamSynchronize(stream));
+    // The sidecars are read by launches on other streams (the partitions' own): a one-off multi-GB build that started with a
+    // device synchronisation also ends with one, instead of an event every partition stream would have to wait for.
+    HIP_TRY(h, hipStreamSynchronize(stream));
     h->se_mode = RANENV_SE_GATHER;
     return RANENV_OK;
 }

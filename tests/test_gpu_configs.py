@@ -222,3 +222,162 @@ def test_full_batch_episode_rollout_over_partitions_equals_single_stream_steps()
         assert torch.equal(va[k], vb[k]), k
     assert torch.equal(oia, oib) and torch.equal(oaa, oab) and torch.equal(ra, rb) and torch.equal(da, db)
     assert bool(db.all()) and int(vb["step_number"].min()) == 1000
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The headline schedule itself against the oracle at full size: BASELINE configs[2] at B = 4096,
+# three batch partitions on three HIP streams, ranenv_rollout with its default launch lengths (several TTIs per launch,
+# staggered first launches, warm entries), compact steps on.  A sample of envs -- from every partition, with at most 64
+# and with more than 64 UEs in slices (one wave / two waves per env in a compact step) -- is mirrored by the CPU oracle
+# and compared after every rollout call: simu.py:555-566 (the MAPF loop), agents/mapf.py:41-111, agents/common.py:558-636.
+# ------------------------------------------------------------------------------------------------------------------
+ROLLOUT_CALLS = (1, 3, 10, 7, 20, 4, 15, 2, 9)            # 71 TTIs: launch boundaries fall differently in every call
+
+
+def _headline_sample(wl, per_class=6):
+    """Env indices: from each of the 3 partitions `per_class` envs whose scenario has <= 64 slice members and
+    `per_class` with > 64, the partitions' first and last envs included."""
+    B = wl.env.B
+    members = (wl.tables.ue_slice[wl.scenario] >= 0).sum(axis=1)
+    base, rem = divmod(B, 3)
+    lo = [0]
+    for k in range(3):
+        lo.append(lo[-1] + base + (1 if k < rem else 0))
+    sample = []
+    for k in range(3):
+        idx = np.arange(lo[k], lo[k + 1])
+        small, big = idx[members[idx] <= 64], idx[members[idx] > 64]
+        assert len(small) >= per_class and len(big) >= per_class
+        pick = lambda a: a[np.unique(np.linspace(0, len(a) - 1, per_class).astype(int))]
+        sample += pick(small).tolist() + pick(big).tolist() + [int(idx[0]), int(idx[-1])]
+    return sorted(set(sample)), members
+
+
+def _compare_with_oracle(env, oenvs, max_pkts, where):
+    """views (raw outputs, queue lengths), both observations and the rewards of the mirrored envs; `max_pkts[b]`: [U]."""
+    g = {k: x.cpu().numpy() for k, x in env.views().items()}
+    oi, oa, rw = env.obs_inter.cpu().numpy(), env.obs_intra.cpu().numpy(), env.reward.cpu().numpy()
+    for b, o in oenvs.items():
+        raw, oo = o.raw(), o.obs()
+        for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+            assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (where, b, name)
+        mp = max_pkts[b].astype(np.float64)
+        assert np.array_equal(g["queue_pkts"][b].astype(np.float64), np.rint(raw["buffer_occupancies"] * mp)), (where, b, "queue_pkts")
+        np.testing.assert_allclose(oi[b], oo["obs_inter"], rtol=0, atol=OBS_TOL, err_msg=str((where, b)))
+        np.testing.assert_allclose(oa[b].reshape(-1), np.asarray(oo["obs_intra"]).reshape(-1), rtol=0, atol=OBS_TOL, err_msg=str((where, b)))
+        np.testing.assert_allclose(rw[b], oo["reward"], rtol=0, atol=REW_TOL, err_msg=str((where, b)))
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_config2_headline_schedule_vs_oracle(se_mode):
+    _need_gpu()
+    from oracle import pyoracle
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(2, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    env = wl.env
+    assert env.B == 4096 and "MAPF" in label and wl.policy == 2 and wl.intra == 1
+    env.set_se_mode(se_mode)
+    env.set_partitions(3)
+    assert env.get_option("compact") == 1 and env.get_option("fuse") in (0, int(__import__("os").environ.get("RANENV_FUSE", "0")))
+    sample, members = _headline_sample(wl)
+    assert len(sample) >= 32 and (members[sample] <= 64).sum() >= 12 and (members[sample] > 64).sum() >= 12
+    S, U, R = env.S, env.U, env.R
+    cfg = pyoracle.make_cfg(S, U, R, env.G, env.Us, bandwidth_hz=env.bandwidth_hz, max_age_cap=env.max_age_cap, max_steps=env.max_steps)
+    eps, L = env.episodes, wl.trace_len
+    tiles = sorted({int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L) for b in sample for t in range(sum(ROLLOUT_CALLS) + 1)})
+    tpos = {t: i for i, t in enumerate(tiles)}
+    se_host = wl.se_pool[torch.as_tensor(tiles, device=env.device)].transpose(1, 2).contiguous().cpu().numpy()   # oracle layout [U][R]
+    trf_host = wl.traffic_pool.cpu().numpy().astype(np.float64)
+    intra = np.full(S, wl.intra, dtype=np.int32)
+    oenvs = {}
+    for b in sample:
+        o = pyoracle.OracleEnv(cfg)
+        o.set_scenario(wl.tables, int(wl.scenario[b]))
+        o.reset(se_host[tpos[int(eps["se_base"][b] + eps["se_offset"][b] % L)]])
+        oenvs[b] = o
+    env.reset()
+    max_pkts = {b: np.asarray(wl.tables.ue_max_pkts)[int(wl.scenario[b])] for b in sample}
+    t = 0
+    for k in ROLLOUT_CALLS:
+        env.rollout(k)
+        for _ in range(k):
+            for b, o in oenvs.items():
+                o.step(o.policy_mapf(), intra, se_host[tpos[int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)]],
+                       trf_host[int(eps["trf_base"][b] + (eps["trf_offset"][b] + t) % L)])
+            t += 1
+        torch.cuda.synchronize()
+        _compare_with_oracle(env, oenvs, max_pkts, (se_mode, "after TTI", t))
+    assert int(env.views()["step_number"].min()) == t == sum(ROLLOUT_CALLS)
+    env.close()
+
+
+def test_config2_headline_schedule_across_an_episode_end_vs_oracle():
+    """The same schedule with device auto-reset: every env's episode (37 TTIs here) ends inside the rollouts, the advance +
+    RESET launches follow that TTI on the partition's own stream, the fused launches end there."""
+    _need_gpu()
+    from oracle import pyoracle
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, _ = make_bench_workload(2, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    env, tabs = wl.env, wl.tables
+    env.set_partitions(3)
+    S, U, R, L, B = env.S, env.U, env.R, wl.trace_len, env.B
+    n_ep, first, ep_len = 50, 0, 37
+    ep_no = np.arange(first, first + n_ep)
+    env.set_episode_table(scenario=(ep_no * 7) % tabs.n_scenarios, se_base=(ep_no % 64) * L, se_len=L, se_offset=(ep_no * 11) % L,
+                          trf_base=((ep_no * 7) % tabs.n_scenarios) * L, trf_len=L, trf_offset=(ep_no * 3) % L, first_episode=first)
+    env.set_max_steps(np.full(B, ep_len, dtype=np.int32))
+    start = first + np.arange(B) % n_ep
+    env.enable_autoreset(first, first + n_ep, random_episodes=False, seed=1, episode_numbers=start)
+    tab = env.episode_table
+    scen_of = lambda ep: int(tab[ep - first]["scenario"])
+    members = np.array([(tabs.ue_slice[scen_of(int(ep))] >= 0).sum() for ep in start])
+    base, rem = divmod(B, 3)
+    sample = []
+    for k in range(3):
+        lo = k * base + min(k, rem)
+        idx = np.arange(lo, lo + base + (1 if k < rem else 0))
+        sample += idx[members[idx] <= 64][:5].tolist() + idx[members[idx] > 64][:5].tolist() + [int(idx[-1])]
+    cfg = pyoracle.make_cfg(S, U, R, env.G, env.Us, bandwidth_hz=env.bandwidth_hz, max_age_cap=env.max_age_cap, max_steps=10 ** 6)
+    se_pool, trf_host = wl.se_pool, wl.traffic_pool.cpu().numpy().astype(np.float64)
+    tile_cache = {}
+
+    def tile(ep, t):
+        r = tab[ep - first]
+        i = int(r["se_base"] + (r["se_offset"] + t) % r["se_len"])
+        if i not in tile_cache:
+            tile_cache[i] = se_pool[i].transpose(0, 1).contiguous().cpu().numpy()
+        return tile_cache[i]
+
+    def trow(ep, t): r = tab[ep - first]; return int(r["trf_base"] + (r["trf_offset"] + t) % r["trf_len"])
+    intra = np.full(S, wl.intra, dtype=np.int32)
+    oenvs, cur, tstep = {}, {}, {}
+    for b in sample:
+        o = pyoracle.OracleEnv(cfg); o.set_scenario(tabs, scen_of(int(start[b]))); o.reset(tile(int(start[b]), 0))
+        oenvs[b], cur[b], tstep[b] = o, int(start[b]), 0
+    env.reset()
+    total = 0
+    for k in (10, 20, 9, 30, 12):                      # 81 TTIs: two episode ends per env (TTIs 37 and 74)
+        env.rollout(k)
+        torch.cuda.synchronize()
+        total += k
+        g = {n: x.cpu().numpy() for n, x in env.views().items()}
+        oi, rw = env.obs_inter.cpu().numpy(), env.reward.cpu().numpy()
+        for b, o in oenvs.items():
+            for _ in range(k):
+                o.step(o.policy_mapf(), intra, tile(cur[b], tstep[b]), trf_host[trow(cur[b], tstep[b])])
+                tstep[b] += 1
+                last = o.obs()
+                if tstep[b] >= ep_len:
+                    cur[b] = cur[b] + 1 if cur[b] + 1 < first + n_ep else first
+                    tstep[b] = 0
+                    o.set_scenario(tabs, scen_of(cur[b])); o.reset(tile(cur[b], 0))
+            np.testing.assert_allclose(rw[b], last["reward"], rtol=0, atol=REW_TOL, err_msg=str((total, b)))
+            assert int(g["episode_number"][b]) == cur[b] and int(g["step_number"][b]) == tstep[b], (total, b)
+            np.testing.assert_allclose(oi[b], o.obs()["obs_inter"], rtol=0, atol=OBS_TOL, err_msg=str((total, b)))
+            raw = o.raw()
+            mp = np.asarray(tabs.ue_max_pkts)[scen_of(cur[b])].astype(np.float64)
+            assert np.array_equal(g["queue_pkts"][b].astype(np.float64), np.rint(raw["buffer_occupancies"] * mp)), (total, b)
+            if tstep[b] > 0:
+                for name in ("pkt_incoming", "pkt_throughputs", "pkt_effective_thr", "dropped_pkts"):
+                    assert np.array_equal(g[name][b].astype(np.float64), raw[name]), (total, b, name)
+    env.close()
