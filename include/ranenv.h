@@ -279,6 +279,9 @@ int ranenv_profile_end(ranenv_handle h, double *avg_ms, int32_t *n_launches);
 /* TTIs covered by the launches timed since ranenv_profile_begin: inside ranenv_rollout one launch may take its envs
  * through several TTIs (see there), so n_ttis / n_launches TTIs went into the average launch. */
 int ranenv_profile_ttis(ranenv_handle h, int64_t *n_ttis);
+/* The same, and the env-TTIs (envs of a launch x its TTIs, summed over the timed launches): with the persistent rollout the
+ * launches of one call differ in how many envs they step. */
+int ranenv_profile_work(ranenv_handle h, int64_t *n_ttis, int64_t *n_env_ttis);
 
 /* Batch partitions: envs are independent, so the batch can be stepped as n_parts contiguous ranges, each by its own
  * launch on its own (handle-owned) HIP stream.  A launch has a ramp and a tail during which CUs idle; with partitions
@@ -377,7 +380,17 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
  *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
  *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one
- *   "persist"      RANENV_PERSIST       0         see ranenv_rollout
+ *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win (SE gather mode, batch above 8 workgroups per
+ *                                                 CU), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
+ *                                                 TTIs up to the next episode end: the envs are sorted by the waves a compact step
+ *                                                 of theirs needs (64 slice members per wave), each class gets a grid of what the
+ *                                                 chip holds, and a workgroup that finishes a chunk of TTIs hands its env over
+ *                                                 (per-XCD ready queues) only when another env is waiting for a slot.  Needs compact
+ *                                                 steps and no bound head outputs (else the rollout runs as described above)
+ *   "persist_chunk" RANENV_PERSIST_CHUNK 10       TTIs of an env between two looks at the queues
+ *   "persist_grid" RANENV_PERSIST_GRID  0         cap on the wave slots the persistent grids are sized for (0 = the occupancy
+ *                                                 query x CUs); small values force hand-overs (tests)
+ *   "persist_errors" (read only)                  waits of a persistent launch that gave up after ~1 s: 0 in every correct run
  *
  * Python host layer only (batched_env.py, not this library): RANENV_SE_MODE=gather makes BatchedRanEnv.bind_se_pool switch
  * to the SE gather mode, RANENV_LIB=<path> loads another build of this library.

@@ -507,11 +507,12 @@ class BatchedRanEnv:
 
     def profile_end(self) -> Dict[str, float]:
         """Average duration in ms of the step-kernel launches since profile_begin: {'step', 'n_launches', 'n_ttis'}
-        (inside rollout() a launch may cover several TTIs: n_ttis / n_launches of them on average)."""
-        ms, n, nt = C.c_double(), C.c_int32(), C.c_int64()
+        (inside rollout() a launch may cover several TTIs: n_ttis / n_launches of them on average; n_env_ttis = envs x TTIs
+        summed over the launches)."""
+        ms, n, nt, ne = C.c_double(), C.c_int32(), C.c_int64(), C.c_int64()
         self._check(self._lib.ranenv_profile_end(self._h, C.byref(ms), C.byref(n)), "ranenv_profile_end")
-        self._check(self._lib.ranenv_profile_ttis(self._h, C.byref(nt)), "ranenv_profile_ttis")
-        return {"step": ms.value, "n_launches": n.value, "n_ttis": nt.value}
+        self._check(self._lib.ranenv_profile_work(self._h, C.byref(nt), C.byref(ne)), "ranenv_profile_work")
+        return {"step": ms.value, "n_launches": n.value, "n_ttis": nt.value, "n_env_ttis": ne.value}
 
     def set_partitions(self, n_parts: int):
         """Step the batch as ``n_parts`` contiguous ranges of envs, each by its own launch on its own stream

@@ -134,6 +134,15 @@ enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 12 };
 #define TB_slice_ues(p) ((p).tab.slice_ues)
 #define TB_slice_usecase(p) ((p).tab.slice_usecase)
 
+// Work queue of the persistent rollout, one set per workgroup class (hot words on lines of their own).
+struct PersistCtl {
+    unsigned fresh[8][32];            // [x][0]: cursor into shard x of the class's env list (entries x, x + 8, x + 16, ...)
+    int remaining; int pad0[31];      // envs of the class that have not finished this launch's TTIs
+    int abort; int pad1[31];          // a wait gave up: every workgroup leaves
+    struct { unsigned head; unsigned pad2[31]; unsigned tail; unsigned pad3[31]; int avail; int pad4[31]; } q[8];   // ready queue of XCD x: head / tail tickets (monotonic), entries committed and not yet claimed
+    unsigned long long stat[8][16];   // per XCD (a line each): [0] chunks kept, [1] pushes, [2] pops, [3] fresh takes, [4] polls that found nothing
+};
+
 struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
     long long BU, NSU, NSL;   // slab strides: B*U, n_scenarios*U, n_scenarios*S*16
@@ -167,6 +176,13 @@ struct KP {
     float *obs_inter; float *obs_intra; double *reward; uint8_t *done;
     // alternative heads (SchedTWC / SchedColORAN), bound by ranenv_bind_head_outputs
     float *head_obs; double *head_reward;
+    // persistent rollout (ranenv_persist_kernel): this launch's workgroup class
+    const int32_t *p_list;            // the class's envs
+    int p_count, p_chunk;             // how many; TTIs of an env between two visits of the work queue
+    struct PersistCtl *p_ctl;         // the class's counters and per-XCD queue heads
+    unsigned long long *p_slots;      // [8][p_cap] queue entries {index + 1, item}
+    int p_cap;                        // entries per queue (a power of two >= the batch)
+    int *p_err;                       // sticky error word of the handle (a wait gave up)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -584,7 +600,7 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
 #if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of thread 0 at up to S phase boundaries of the step
                           kernel, dumped into policy_scores[e][k] instead of the scores (tools/stamps.py) */
 #define RANENV_STAMP(k) do { if (threadIdx.x == 0 && (k) < p.S) \
-    ST_policy_scores(p)[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+    ST_policy_scores(p)[(size_t)e * p.S + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RANENV_STAMP(k) do { } while (0)
 #endif
@@ -884,18 +900,21 @@ struct StepCarry {
     double sem_prev;
 };
 
-template <int MODE, int NQ, bool GATHER, int NP, typename P>
-DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm)   // warm: `cy` holds what the previous TTI of this launch left
+template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, typename P>
+DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)   // warm: `cy` holds what the previous TTI of this launch left
 {                                     // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     __shared__ SharedCore<NP> sh;
     auto &xr = sh.xr;
-    int e_ = p.e0 + blockIdx.x, tid_ = threadIdx.x;
+    int e_ = e_in, tid_ = threadIdx.x;      // e_in: p.e0 + blockIdx.x, or the env a persistent workgroup took from its queue
     // (opaque to the optimiser: inside step_loop nothing derived from them is carried from one TTI to the next in registers)
     asm volatile("" : "+s"(e_));
     asm volatile("" : "+v"(tid_));
     const int e = e_, tid = tid_;
-    if (p.env_mask != nullptr && p.env_mask[e] == 0) return true;  // uniform per workgroup
+    // (inside a persistent launch no thread ever leaves the body early -- there is no env mask inside a rollout and every wave
+    // is needed again for the next env --, and the exits are compiled out: a divergent way out of the persistent loops would
+    // make the loop-carried wave-uniform values divergent in the compiler's eyes)
+    if (!PERSIST && p.env_mask != nullptr && p.env_mask[e] == 0) return true;  // uniform per workgroup
     const int S = p.S, U = p.U, R = p.R, D = p.D, Us = p.Us;
     const int W = 2 * Us + 9;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -970,7 +989,9 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm)   // warm: `cy`
     }
 #undef TBL
     const bool act = tid < U && !(compact && slc < 0);
-    if (!warm && compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;     // (wave 0 stays: it runs the slice roles)
+    // (wave 0 stays: it runs the slice roles; inside a persistent launch every wave stays -- the launch's blocks have as many
+    // waves as the env's class needs)
+    if (!PERSIST && !warm && compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;
     const size_t er4 = (size_t)e * U * 4, er8 = (size_t)e * U * 8;      // this env's row of a per-UE array of 4- / 8-byte elements
     const unsigned u4 = (unsigned)u * 4u, u8 = (unsigned)u * 8u;
 #define UE4(f) row_at(ST_##f(p), er4, u4)
@@ -1545,7 +1566,7 @@ DEVFN void step_loop(const KP &p)
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
-            if (step_body<MODE, NQ, GATHER, NP>(*kc, cy, warm)) return;
+            if (step_body<MODE, NQ, GATHER, NP>(*kc, cy, warm, kc->e0 + (int)blockIdx.x)) return;
             if (k + 1 < n) {
                 // The next TTI takes over in registers what it would otherwise load back (StepCarry) -- unless it has to look
                 // for an allocation made ahead (RANENV_LATE) -- and then only LDS has to be handed over between the waves.
@@ -1555,10 +1576,221 @@ DEVFN void step_loop(const KP &p)
         }
     } else {
         StepCarry cy = {};
-        step_body<MODE, NQ, GATHER, NP>(p, cy, false);
+        step_body<MODE, NQ, GATHER, NP>(p, cy, false, p.e0 + (int)blockIdx.x);
     }
 }
 #undef COLD
+
+// =============================================================================================
+// Persistent rollout (option "persist"): ONE launch per workgroup class takes every env of the batch through all the TTIs of
+// a ranenv_rollout call (up to the next episode end).  Why: a launch of one workgroup per env wants more slots than the chip
+// has (4096 envs, ~3700 slots at the headline size), the workgroups that waited run last and alone, and every launch
+// boundary pays that drain again (profiles/r03_ab_log.txt: a batch that is resident at once steps 10 % faster).  Here the
+// grid is what fits, and a workgroup that finishes a chunk of TTIs of its env looks whether anybody is waiting:
+//   * envs nobody has started yet (`fresh`: cursors over the class's env list, one shard per XCD label, taken first), or
+//   * envs that another workgroup of THIS XCD has put down between two chunks (the XCD's ready queue);
+//   if so it puts its env down (pushes it on its XCD's ready queue) and takes the waiting one, else it carries on with its
+//   own env -- warm, registers and all -- so that a batch that is resident at once never touches the queues.
+// Classes: a compact step needs one wave per 64 slice members of the env's scenario (lanes are ordered members first), and a
+// wave that idles through a persistent launch would hold a wave slot for nothing; so the envs are sorted by the waves they
+// need (ranenv_persist_classify_kernel) and each class gets a launch of its own with blocks of that many waves.
+// Hand-over between workgroups: per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another
+// CU's stores (MI355X_MICROARCH.md, Workgroup dispatch).  An env is therefore bound to the XCD that first touched it
+// in this launch (fresh envs were last written by an earlier kernel: visible everywhere): its later chunks go through
+// that XCD's own queue, producer and consumer share the L2, the producer's stores are acknowledged by that L2 before the push
+// (s_waitcnt vmcnt(0) in every wave, workgroup barrier), and the consumer invalidates its CU's L1 (agent-scope acquire)
+// behind the pop, before any wave of it loads.  The XCD is read from HW_REG_XCC_ID, not inferred from blockIdx.
+// Nobody waits for work: a workgroup that finds no fresh env and its XCD's queue empty leaves (persist_pull says why that is
+// safe).  The one spin -- on a queue entry whose pusher holds the ticket but has not written it yet -- is bounded (sticky error
+// word, every workgroup leaves).
+// =============================================================================================
+struct PersistLocal { int item, next, keep, fresh_mask, xcc, pad; };
+enum { PERSIST_EXIT = -1, PERSIST_NONE = -2 };
+enum { PERSIST_ENV_BITS = 20 };           // item = env | TTIs done << 20
+
+// (statistics of the queues, one fire-and-forget add per event from lane 0: ranenv_get_option "persist_stat_*")
+#define PSTAT(k) ((void)__hip_atomic_fetch_add(&p.p_ctl->stat[pl.xcc][k], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+DEVFN unsigned pq_ld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN int pq_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// lane 0 only.  -> item, or PERSIST_NONE
+template <typename P> DEVFN int persist_try_fresh(const P &p, PersistLocal &pl)
+{
+    PersistCtl *c = p.p_ctl;
+    for (int s8 = 0; s8 < 8 && pl.fresh_mask != 0; s8++) {
+        const int x = (pl.xcc + s8) & 7;
+        if (!(pl.fresh_mask >> x & 1)) continue;
+        const unsigned j = __hip_atomic_fetch_add(&c->fresh[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long i = (long long)x + 8ll * (long long)j;
+        if (i < (long long)p.p_count) { PSTAT(3); return p.p_list[i]; }  // (TTIs done: 0)
+        pl.fresh_mask &= ~(1 << x);
+    }
+    return PERSIST_NONE;
+}
+
+// lane 0 only.  -> item (L1 of this CU invalidated behind the pop), PERSIST_NONE if nothing is committed to the queue.
+// Three words per queue, no compare-and-swap: `avail` counts committed entries nobody has claimed (a semaphore: whoever takes it
+// from > 0 owns exactly one entry, whoever finds it <= 0 gives it back and goes), `head` hands the claimed entries out in
+// order, `tail` hands out the slots to write.  A claimed slot may still be in the hands of its pusher (ticket taken, store on
+// its way): the claimer spins on that slot's tag, a bounded wait.  (The first version popped by compare-and-swap on `head`:
+// three dependent loads and the swap per attempt, and with a few hundred workgroups of an XCD at the queue 35 of 36 attempts
+// lost -- profiles/r04_ab_log.txt.)
+template <typename P> DEVFN int persist_try_pop(const P &p, const PersistLocal &pl)
+{
+    PersistCtl *c = p.p_ctl;
+    if (pq_ldi(&c->q[pl.xcc].avail) <= 0) return PERSIST_NONE;
+    const int a = __hip_atomic_fetch_add(&c->q[pl.xcc].avail, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a <= 0) { __hip_atomic_fetch_add(&c->q[pl.xcc].avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return PERSIST_NONE; }
+    const unsigned h = __hip_atomic_fetch_add(&c->q[pl.xcc].head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *slot = p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (h & (unsigned)(p.p_cap - 1));
+    unsigned long long ent = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spin = 0; (unsigned)(ent >> 32) != h + 1u; spin++) {
+        PSTAT(4);
+        if (spin > (1u << 22) || pq_ldi(&c->abort) != 0) {               // seconds on one slot: never in a correct run
+            __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.p_err) __hip_atomic_fetch_add(p.p_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return PERSIST_EXIT;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        ent = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    PSTAT(2);
+#ifndef RANENV_PERSIST_NO_ACQUIRE      /* timing experiments only: results may be stale without it */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // buffer_inv sc1: this CU's L1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    return (int)(unsigned)ent;
+}
+
+template <typename P> DEVFN void persist_push(const P &p, const PersistLocal &pl, int item)
+{
+    PersistCtl *c = p.p_ctl;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the workgroup's stores were waited for before the barrier)
+    const unsigned idx = __hip_atomic_fetch_add(&c->q[pl.xcc].tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *slot = p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (idx & (unsigned)(p.p_cap - 1));
+    __hip_atomic_store(slot, ((unsigned long long)(idx + 1u) << 32) | (unsigned)item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&c->q[pl.xcc].avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PSTAT(1);
+}
+
+// lane 0 only: the next env of this workgroup -> item or PERSIST_EXIT.
+// A workgroup that finds no fresh env and nothing committed to its XCD's queue LEAVES; it does not wait.  Nothing it would
+// have to serve can be lost: an env is put down only by a workgroup that stays alive and comes back to the queue (at its next
+// chunk end, or when its own env is through: it leaves only past an empty queue), so an env on a queue always has a live
+// workgroup of its XCD.  (The first version polled here until the class had finished: a few hundred sleeping workgroups
+// polling three words of HBM-side state every microsecond cost the running ones a factor of four, profiles/r04_ab_log.txt.)
+// The freed slots go to the grid's workgroups that did not fit at first.
+template <typename P> DEVFN int persist_pull(const P &p, PersistLocal &pl)
+{
+    if (pl.next != PERSIST_NONE) { const int it = pl.next; pl.next = PERSIST_NONE; return it; }
+    int it = persist_try_fresh(p, pl);
+    if (it != PERSIST_NONE) return it;
+    it = persist_try_pop(p, pl);
+    return it != PERSIST_NONE ? it : PERSIST_EXIT;
+}
+
+// lane 0 only, behind the barrier that follows a chunk: -> 1 the workgroup keeps its env, 0 it has let go of it
+template <typename P> DEVFN int persist_finish(const P &p, PersistLocal &pl, int e, int done, int n_tti)
+{
+    PersistCtl *c = p.p_ctl;
+    if (done >= n_tti) { __hip_atomic_fetch_add(&c->remaining, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+    if (pq_ldi(&c->abort) != 0) return 0;
+    const int fresh = persist_try_fresh(p, pl);
+    if (fresh == PERSIST_NONE) {
+        if (pq_ldi(&c->q[pl.xcc].avail) <= 0) { PSTAT(0); return 1; }    // nobody is waiting
+        const unsigned h = pq_ld(&c->q[pl.xcc].head);
+        // Somebody is -- but a swap only helps when the env at the head of the queue is BEHIND this one: with every
+        // finisher swapping, every chunk of every env would go through the queue; this way a round of chunks costs one swap per
+        // waiting env (a racy look at the head entry: a heuristic, whichever way it goes the state stays consistent).
+        const unsigned long long ent = __hip_atomic_load(p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (h & (unsigned)(p.p_cap - 1)),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(ent >> 32) == h + 1u && (int)((unsigned)ent >> PERSIST_ENV_BITS) >= done) { PSTAT(0); return 1; }
+    }
+    pl.next = fresh;
+    persist_push(p, pl, e | (done << PERSIST_ENV_BITS));
+    return 0;
+}
+
+template <int NQ, bool GATHER, int NP>
+DEVFN void persist_loop()
+{
+    typedef const __attribute__((address_space(4))) KP *kp_const_t;
+    __shared__ PersistLocal pl;
+    const int tid0 = threadIdx.x;
+    if (tid0 == 0) {
+        pl.next = PERSIST_NONE; pl.fresh_mask = 0xff; pl.keep = 0;
+        pl.xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);      // HW_REG_XCC_ID, bits 3:0
+    }
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    for (;;) {
+        {
+            kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kc));
+            if (tid0 == 0) pl.item = persist_pull(*kc, pl);
+        }
+        __syncthreads();
+        const int item = uni(pl.item);
+        if (item < 0) return;
+        const int e = item & ((1 << PERSIST_ENV_BITS) - 1);
+        int done = (int)((unsigned)item >> PERSIST_ENV_BITS);
+        StepCarry cy = {};
+        bool warm = false;
+        for (;;) {                                   // chunks of this env for as long as nobody is waiting
+            kp_const_t kc0 = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kc0));
+            const int n_tti = kc0->n_tti, left = n_tti - done;
+            // (an env's first chunk is 1..chunk TTIs long by a hash of its index: the workgroups of a launch start together, and
+            // chunks of one length would bring all of them to the queues at the same moments)
+            int want = kc0->p_chunk;
+            if (done == 0 && want > 1) want = 1 + (int)((((unsigned)e * 0x9E3779B1u) >> 16) % (unsigned)want);
+            const int n = left < want ? left : want;
+            for (int k = 0; k < n; k++) {
+                kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kc));
+                (void)step_body<MODE_STEP, NQ, GATHER, NP, true>(*kc, cy, warm, e);
+                if (k + 1 < n) { warm = RANENV_WARM_ENTRY != 0; if (warm) wg_sync(); else __syncthreads(); }
+            }
+            done += n;
+            __syncthreads();                         // every wave's stores are acknowledged (vmcnt(0)) and every wave is here
+            if (tid0 == 0) {
+                kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kc));
+                pl.keep = persist_finish(*kc, pl, e, done, n_tti);
+            }
+            __syncthreads();
+            if (uni(pl.keep) == 0) break;
+            warm = RANENV_WARM_ENTRY != 0;           // `cy` is what the chunk's last TTI left
+        }
+    }
+}
+
+template <bool GATHER, int NP>
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(5, 5))) ranenv_persist_kernel(const KP p)
+{
+    (void)p;                                         // (read in place, like step_loop)
+    persist_loop<GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP>();
+}
+
+// Sort the envs by the waves a compact step of theirs needs: class c = ceil(slice members of the env's scenario / 64) - 1.
+__global__ void __launch_bounds__(256) ranenv_persist_classify_kernel(const ranenv_episode *eps, const int32_t *members, int B, int n_class,
+                                                                      int32_t *list, int32_t *count)
+{
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= B) return;
+    const int m = members[eps[e].scenario];
+    int c = m <= 0 ? 0 : (m + WAVE - 1) / WAVE - 1;
+    c = c < n_class ? c : n_class - 1;
+    const int pos = atomicAdd(&count[c], 1);
+    list[(size_t)c * B + pos] = e;
+}
+// Per launch: the class's cursors and its count of unfinished envs (queue heads and tails are monotonic: never reset).
+__global__ void __launch_bounds__(64) ranenv_persist_prep_kernel(PersistCtl *ctl, const int32_t *count, int n_class)
+{
+    const int c = (int)blockIdx.x, t = (int)threadIdx.x;
+    if (c >= n_class) return;
+    if (t < 8) ctl[c].fresh[t][0] = 0u;
+    if (t == 8) { ctl[c].remaining = count[c]; ctl[c].abort = 0; }
+}
 
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
 // 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 16 SE loads in flight per lane (8 until the build stopped hoisting
@@ -1926,8 +2158,17 @@ struct ranenv {
     int se_mode = RANENV_SE_STREAM;
     double *d_se_mean = nullptr; float *d_se_um = nullptr; int se_rp = 0;
     // compact steps (KP::compact): allowed while UEs outside every slice provably receive no traffic
-    bool persist = false;          // ranenv_rollout as one persistent work-queue launch per workgroup class (option "persist")
+    int persist = -1;              // ranenv_rollout as one persistent work-queue launch per workgroup class (option "persist"):
+                                   // 0 never, 1 whenever possible, -1 (default) where it was measured to win: SE gather mode with a
+                                   // batch that fills the CUs
     int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
+    int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
+    std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
+    int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
+    int *d_perr = nullptr; int p_nclass = 0, p_cap = 0;
+    std::vector<int32_t> pcount_host; bool pclass_dirty = true;
+    int p_wave_slots[2] = {0, 0};  // wave slots per CU of the persistent kernel (streaming, gather build), from the occupancy query
+    long long prof_env_ttis = 0;   // env-TTIs covered by the launches timed since ranenv_profile_begin
     int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
     std::vector<int> fuse_first;   // override of the length of partition k's first launch of a rollout (RANENV_FUSE_FIRST=a,b,c)
     long long prof_ttis = 0;       // TTIs covered by the launches timed since ranenv_profile_begin
@@ -2094,6 +2335,7 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         ev0 = h->prof_ev[h->prof_used]; ev1 = h->prof_ev[h->prof_used + 1];
         h->prof_used += 2;
         h->prof_ttis += MODE == MODE_STEP ? kp.n_tti : 1;
+        h->prof_env_ttis += (long long)n * (MODE == MODE_STEP ? kp.n_tti : 1);
     }
     switch (h->np) {
     case 8: launch_kernels<MODE, 8>(h, kp, grid, block, stream, ev0, ev1, gather); break;
@@ -2224,6 +2466,147 @@ AdvanceArgs advance_args(ranenv_handle h, const uint8_t *dev_done, float *obs_in
     return a;
 }
 
+int max_steps_of_env(ranenv_handle h, int b) { return h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b]; }
+
+// ---- persistent rollout (option "persist"), host side ------------------------------------------------------------
+hipError_t ensure_streams(ranenv_handle h, size_t n)      // handle-owned streams / events [1, n) exist (index 0 = the caller's stream)
+{
+    while (h->part_stream.size() < n) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        h->part_stream.push_back(st);
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        h->part_done.push_back(ev);
+        ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        h->part_in.push_back(ev);
+    }
+    if (!h->ev_in) return hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming);
+    return hipSuccess;
+}
+
+template <bool GATHER>
+const void *persist_kernel_of(int np)
+{
+    switch (np) {
+    case 8: return reinterpret_cast<const void *>(&ranenv_persist_kernel<GATHER, 8>);
+    case 10: return reinterpret_cast<const void *>(&ranenv_persist_kernel<GATHER, 10>);
+    default: return reinterpret_cast<const void *>(&ranenv_persist_kernel<GATHER, 16>);
+    }
+}
+
+template <bool GATHER, int NP>
+void launch_persist_of(const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (ev0) hipExtLaunchKernelGGL((ranenv_persist_kernel<GATHER, NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+    else hipLaunchKernelGGL((ranenv_persist_kernel<GATHER, NP>), grid, block, 0, stream, kp);
+}
+template <bool GATHER>
+void launch_persist(int np, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1)
+{
+    switch (np) {
+    case 8: launch_persist_of<GATHER, 8>(kp, grid, block, stream, ev0, ev1); break;
+    case 10: launch_persist_of<GATHER, 10>(kp, grid, block, stream, ev0, ev1); break;
+    default: launch_persist_of<GATHER, 16>(kp, grid, block, stream, ev0, ev1); break;
+    }
+}
+
+// The buffers of the work queues (once per handle) and, whenever scenarios / episodes changed, the envs sorted by class.
+int persist_prepare(ranenv_handle h, hipStream_t stream)
+{
+    const int B = h->cfg.batch, NC = h->nt / WAVE;
+    if (!h->d_plist) {
+        int cap = 64;
+        while (cap < B) cap <<= 1;
+        h->p_nclass = NC; h->p_cap = cap;
+        if (dev_alloc(h, &h->d_plist, (size_t)NC * B) != RANENV_OK || dev_alloc(h, &h->d_pcount, (size_t)NC) != RANENV_OK ||
+            dev_alloc(h, &h->d_pctl, (size_t)NC) != RANENV_OK || dev_alloc(h, &h->d_pslots, (size_t)NC * 8 * (size_t)cap) != RANENV_OK ||
+            dev_alloc(h, &h->d_perr, 1) != RANENV_OK)
+            return RANENV_E_NOMEM;
+        h->pcount_host.assign((size_t)NC, 0);
+        h->pclass_dirty = true;
+    }
+    if (h->pclass_dirty) {
+        HIP_TRY(h, hipMemsetAsync(h->d_pcount, 0, sizeof(int32_t) * (size_t)NC, stream));
+        hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes,
+                           h->d_members, B, NC, h->d_plist, h->d_pcount);
+        HIP_TRY(h, hipMemcpyAsync(h->pcount_host.data(), h->d_pcount, sizeof(int32_t) * (size_t)NC, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        h->pclass_dirty = false;
+    }
+    return RANENV_OK;
+}
+
+// One persistent launch per non-empty class for `n_tti` TTIs of every env: the class with the widest blocks on the caller's
+// stream (enqueued first: a block of several waves needs that many free slots on one CU), the others on handle-owned streams
+// between an event pair.
+int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
+{
+    const int B = h->cfg.batch, NC = h->p_nclass;
+    const bool gather = h->se_mode == RANENV_SE_GATHER;
+    kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0;
+    kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->d_perr;
+    if (gather) {
+        kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
+        kp.se_mean_pool = h->d_se_mean; kp.se_rp = h->se_rp;
+    }
+    int &slots_cu = h->p_wave_slots[gather ? 1 : 0];
+    if (slots_cu == 0) {
+        int nb = 0;
+        const void *fn = gather ? persist_kernel_of<true>(h->np) : persist_kernel_of<false>(h->np);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVE, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 16; }
+        slots_cu = nb;
+    }
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    long long W = (long long)slots_cu * cus, demand = 0;
+    if (h->persist_grid > 0 && h->persist_grid < W) W = h->persist_grid;
+    int n_used = 0;
+    for (int c = 0; c < NC; c++) { demand += (long long)h->pcount_host[(size_t)c] * (c + 1); n_used += h->pcount_host[(size_t)c] > 0 ? 1 : 0; }
+    if (demand == 0) return RANENV_OK;
+    hipError_t e = ensure_streams(h, (size_t)(n_used > 1 ? n_used : 1));
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout, streams: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(ranenv_persist_prep_kernel, dim3((unsigned)NC), dim3(64), 0, stream, h->d_pctl, h->d_pcount, NC);
+    if (n_used > 1) HIP_TRY(h, hipEventRecord(h->ev_in, stream));
+    int k = 0;                                     // stream index: 0 = the caller's
+    for (int c = NC - 1; c >= 0; c--) {
+        const int n = h->pcount_host[(size_t)c];
+        if (n == 0) continue;
+        long long g = demand <= W ? n : (long long)n * W / demand;
+        if (g < 1) g = 1;
+        if (g > n) g = n;
+        hipStream_t s = k == 0 ? stream : h->part_stream[(size_t)k];
+        if (k > 0) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_in, 0));
+        KP kc = kp;
+        kc.p_list = h->d_plist + (size_t)c * B; kc.p_count = n; kc.p_ctl = h->d_pctl + c;
+        kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (h->prof_on) {
+            while (h->prof_ev.size() < h->prof_used + 2) {
+                hipEvent_t pe = nullptr;
+                HIP_TRY(h, hipEventCreate(&pe));
+                h->prof_ev.push_back(pe);
+            }
+            ev0 = h->prof_ev[h->prof_used]; ev1 = h->prof_ev[h->prof_used + 1];
+            h->prof_used += 2; h->prof_ttis += n_tti; h->prof_env_ttis += (long long)n * n_tti;
+        }
+        const dim3 grid((unsigned)g), block((unsigned)((c + 1) * WAVE));
+        if (gather) launch_persist<true>(h->np, kc, grid, block, s, ev0, ev1);
+        else launch_persist<false>(h->np, kc, grid, block, s, ev0, ev1);
+        if (k > 0) HIP_TRY(h, hipEventRecord(h->part_done[(size_t)k], s));
+        k++;
+    }
+    for (int j = 1; j < k; j++) HIP_TRY(h, hipStreamWaitEvent(stream, h->part_done[(size_t)j], 0));
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout launch: %s", hipGetErrorString(e));
+    if (h->cfg.flags & RANENV_F_SYNC_CHECK) HIP_TRY(h, hipStreamSynchronize(stream));
+    return RANENV_OK;
+}
+
 // Tuning / debug options (include/ranenv.h, "Options"): ONE setter behind ranenv_set_option, and ONE place where the
 // process environment is read (ranenv_create -> apply_env_options: RANENV_<KEY IN CAPITALS>=value presets the same
 // options for handles created afterwards; the test suite and the A/B tools run whole passes under them).
@@ -2241,8 +2624,9 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
         return RANENV_OK;
     }
     if (k == "small_batch") { h->small_batch = v != 0; return RANENV_OK; }
-    if (k == "persist") { h->persist = v != 0; return RANENV_OK; }
+    if (k == "persist") { h->persist = v < 0 ? -1 : (v != 0 ? 1 : 0); return RANENV_OK; }
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
+    if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -2254,7 +2638,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk"};
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -2330,7 +2714,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
     ALLOC(kp.st.next_scores, B * S);
-    ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B);
+    ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B); ALLOC(h->d_members, NS);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
@@ -2372,8 +2756,28 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "late") *value = h->kp.late;
     else if (k == "row_width") *value = h->np;
     else if (k == "small_batch") *value = h->small_batch ? 1 : 0;
-    else if (k == "persist") *value = h->persist ? 1 : 0;
+    else if (k == "persist") *value = h->persist;
     else if (k == "persist_chunk") *value = h->persist_chunk;
+    else if (k == "persist_grid") *value = h->persist_grid;
+    else if (k.rfind("persist_stat_", 0) == 0) {      // keep / push / pop / fresh / idle_polls, summed over classes and XCDs
+        static const char *const names[] = {"keep", "push", "pop", "fresh", "idle_polls"};
+        int which = -1;
+        for (int i = 0; i < 5; i++) if (k == std::string("persist_stat_") + names[i]) which = i;
+        if (which < 0) return fail(h, RANENV_E_INVALID, "unknown option '%s'", key);
+        long long tot = 0;
+        if (h->d_pctl) {
+            HIP_TRY(h, hipSetDevice(h->cfg.device)); HIP_TRY(h, hipDeviceSynchronize());
+            std::vector<PersistCtl> ctl((size_t)h->p_nclass);
+            HIP_TRY(h, hipMemcpy(ctl.data(), h->d_pctl, sizeof(PersistCtl) * ctl.size(), hipMemcpyDeviceToHost));
+            for (auto &c : ctl) for (int x = 0; x < 8; x++) tot += (long long)c.stat[x][which];
+        }
+        *value = tot;
+    }
+    else if (k == "persist_errors") {          // sticky: waits of a persistent launch that gave up (0 in every correct run)
+        int v = 0;
+        if (h->d_perr) { HIP_TRY(h, hipSetDevice(h->cfg.device)); HIP_TRY(h, hipDeviceSynchronize()); HIP_TRY(h, hipMemcpy(&v, h->d_perr, sizeof(int), hipMemcpyDeviceToHost)); }
+        *value = v;
+    }
     else if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9')
         *value = (size_t)(k[10] - '0') < h->fuse_first.size() ? h->fuse_first[(size_t)(k[10] - '0')] : 0;
     else return fail(h, RANENV_E_INVALID, "unknown option '%s'", key);
@@ -2465,6 +2869,13 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
             }
     }
     h->idle_check_dirty = true;                 // which UEs are idle changed: traffic traces are re-examined before compact steps
+    if (h->members_host.size() != (size_t)h->cfg.n_scenarios) h->members_host.assign((size_t)h->cfg.n_scenarios, 0);
+    for (size_t i = 0; i < n; i++) {
+        int m = 0;
+        for (int ue = 0; ue < U; ue++) m += t->ue_slice[i * U + ue] >= 0 ? 1 : 0;
+        h->members_host[(size_t)first + i] = m;
+    }
+    h->pclass_dirty = true;
     const size_t f = (size_t)first;
     const Tables &d = h->kp.tab;
     const KP &k = h->kp;
@@ -2492,6 +2903,7 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
         PUT(TB_lane_ue(k) + set1 + f * U, ident.data(), n * U, int32_t);
         HIP_TRY(h, hipStreamSynchronize(stream));          // `ident` dies here
     }
+    PUT(h->d_members + f, h->members_host.data() + f, n, int32_t);
     PUT(TB_slot_ue(k) + f * NSL, sue.data(), n * NSL, int32_t);
     PUT(TB_slot_mp(k) + f * NSL, smp.data(), n * NSL, int32_t);
     PUT(TB_slot_pk(k) + f * NSL, spk.data(), n * NSL, int32_t);
@@ -2546,7 +2958,7 @@ int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *eps, void *stream
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(h->d_episodes, eps, sizeof(ranenv_episode) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
-    h->have_episodes = true; h->alloc_gen++; h->idle_check_dirty = true;
+    h->have_episodes = true; h->alloc_gen++; h->idle_check_dirty = true; h->pclass_dirty = true;
     return RANENV_OK;
 }
 
@@ -2745,7 +3157,7 @@ int ranenv_profile_begin(ranenv_handle h)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    h->prof_used = 0; h->prof_ttis = 0; h->prof_on = true;
+    h->prof_used = 0; h->prof_ttis = 0; h->prof_env_ttis = 0; h->prof_on = true;
     return RANENV_OK;
 }
 
@@ -2753,6 +3165,14 @@ int ranenv_profile_ttis(ranenv_handle h, int64_t *n_ttis)
 {
     if (!h || !n_ttis) return fail(h, RANENV_E_INVALID, "null argument");
     *n_ttis = (int64_t)h->prof_ttis;
+    return RANENV_OK;
+}
+
+int ranenv_profile_work(ranenv_handle h, int64_t *n_ttis, int64_t *n_env_ttis)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    if (n_ttis) *n_ttis = (int64_t)h->prof_ttis;
+    if (n_env_ttis) *n_env_ttis = (int64_t)h->prof_env_ttis;
     return RANENV_OK;
 }
 
@@ -2831,6 +3251,40 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
         kpr.head_reward = nullptr;               // the terminal transition's head rewards stay, like reward / done
     }
     const bool follow = h->ar_on;
+    // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
+    // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
+    // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
+    const bool persist_wanted = h->persist == 1 || (h->persist < 0 && h->se_mode == RANENV_SE_GATHER && !h->small_batch);
+    if (persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0) {
+        for (int done_ttis = 0; done_ttis < n_steps;) {
+            int n_tti = n_steps - done_ttis;
+            if (follow) {
+                for (int b = 0; b < h->cfg.batch; b++) {
+                    const int d = max_steps_of_env(h, b) - steps[(size_t)b];
+                    if (d < n_tti) n_tti = d;
+                }
+                if (n_tti < 1) n_tti = 1;
+            }
+            if (n_tti >= (1 << (31 - PERSIST_ENV_BITS))) n_tti = (1 << (31 - PERSIST_ENV_BITS)) - 1;
+            rc = persist_prepare(h, stream);
+            if (rc != RANENV_OK) return rc;
+            rc = persist_launch(h, kp, n_tti, stream);
+            if (rc != RANENV_OK) return rc;
+            done_ttis += n_tti;
+            if (!follow) continue;
+            bool any = false;
+            for (int b = 0; b < h->cfg.batch; b++) {
+                steps[(size_t)b] += n_tti;
+                if (steps[(size_t)b] >= max_steps_of_env(h, b)) { any = true; steps[(size_t)b] = 0; }
+            }
+            if (!any) continue;
+            h->pclass_dirty = true;               // the restarted envs' scenarios
+            hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, adv);
+            const hipError_t re = launch_range<MODE_RESET>(h, kpr, 0, h->cfg.batch, stream);
+            if (re != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout, reset launch: %s", hipGetErrorString(re));
+        }
+        return RANENV_OK;
+    }
     // A launch takes its envs through several TTIs where nothing has to happen in between (see step_loop): no head kernel
     // behind every step, and -- with auto-reset -- no episode end before the launch's last TTI.  How many: a quarter of
     // the rollout, at most 10 (measured, profiles/r03_ab_log.txt: longer launches gain nothing more and lengthen the
@@ -2885,6 +3339,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
             }
             if (!any) return hipSuccess;
             AdvanceArgs a = adv; a.e0 = e0;
+            h->pclass_dirty = true;
             hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
             return launch_range<MODE_RESET>(h, kpr, e0, n, s);
         });
@@ -3029,6 +3484,7 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
     const AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
+    h->pclass_dirty = true;                      // (scenarios of the restarted envs)
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
@@ -3057,6 +3513,7 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
     const int e0 = h->part_lo[(size_t)part], n = h->part_lo[(size_t)part + 1] - e0;
     AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
     a.e0 = e0;
+    h->pclass_dirty = true;
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, ps, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;

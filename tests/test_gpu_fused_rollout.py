@@ -138,3 +138,89 @@ def test_fused_rollout_with_the_traffic_drawn_on_the_device(monkeypatch):
     _same(a, b, "philox")
     assert int(a.views()["pkt_incoming"].sum()) > 0
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------------------------- persistent rollout
+def _persist_pair(B, se_mode, setup, **opts):
+    """Two identical workloads: `a` with the default rollout schedule, `b` with option persist (+ opts)."""
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    out = []
+    for persist in (0, 1):
+        wl = make_mult_slice_workload(B, torch.device("cuda", 0), n_scenarios=32, n_traces=16, trace_len=24, max_steps=1000)
+        wl.env.set_se_mode(se_mode)
+        setup(wl)
+        wl.env.set_option("persist", persist)
+        if persist:
+            for k, v in opts.items():
+                wl.env.set_option(k, v)
+        out.append(wl)
+    return out
+
+
+def _same_state(a, b, where):
+    va, vb = a.env.views(), b.env.views()
+    scen = va["episodes"][:, 0].to(torch.int64)                 # as on the device: auto-reset may have moved on
+    in_slice = torch.as_tensor(a.tables.ue_slice >= 0, device=a.env.device)[scen]
+    for k in va:
+        if k == "se_mean":                                      # of UEs outside every slice: not kept up by compact steps
+            assert torch.equal(va[k][in_slice], vb[k][in_slice]), (where, k)
+        else:
+            assert torch.equal(va[k], vb[k]), (where, k)
+    assert torch.equal(a.env.obs_inter, b.env.obs_inter) and torch.equal(a.env.obs_intra, b.env.obs_intra), where
+    assert torch.equal(a.env.reward, b.env.reward) and torch.equal(a.env.done, b.env.done), where
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+@pytest.mark.parametrize("B,opts", [(300, {}),                                           # everything resident: nobody ever waits
+                                    (300, {"persist_grid": 96, "persist_chunk": 3}),      # ~4 envs per workgroup: hand-overs all the time
+                                    (4096, {}),                                           # the headline batch on the real grid
+                                    (4096, {"persist_grid": 1500, "persist_chunk": 2}),
+                                    (1000, {"persist_grid": 8, "persist_chunk": 1})])     # a handful of workgroups, one per XCD or fewer
+def test_persistent_rollout_equals_the_launch_per_chunk_rollout(se_mode, B, opts):
+    """Option persist: one persistent work-queue launch per workgroup class (one wave / two waves per env) instead of launches of
+    <= 10 TTIs per partition.  Same numbers bit for bit after every call, whatever the grid: with a grid far smaller than the
+    batch every chunk of every env is handed from one workgroup to another through the per-XCD ready queues (stale-L1 and
+    cross-XCD hazards would show up as wrong state here), with the default grid the queues are hardly touched."""
+    _need_gpu()
+    a, b = _persist_pair(B, se_mode, lambda wl: wl.env.set_partitions(3), **opts)
+    a.env.reset(); b.env.reset()
+    t = 0
+    for k in (1, 7, 23, 10, 40, 3):
+        a.env.rollout(k); b.env.rollout(k)
+        torch.cuda.synchronize()
+        t += k
+        _same_state(a, b, (se_mode, B, t))
+    a.env.step(); b.env.step()                              # a joined step behind a persistent rollout, then another rollout
+    a.env.rollout(12); b.env.rollout(12)
+    torch.cuda.synchronize()
+    _same_state(a, b, (se_mode, B, "tail"))
+    assert b.env.get_option("persist_errors") == 0
+    a.env.close(); b.env.close()
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_persistent_rollout_through_episode_ends(se_mode):
+    """With device auto-reset a persistent launch ends at the TTI at which the first episode of the batch ends; the advance +
+    RESET launches follow and the envs are sorted into classes again (their scenarios changed).  Per-env episode lengths."""
+    _need_gpu()
+    B, n_ep = 600, 40
+
+    def setup(wl):
+        env = wl.env
+        ep = np.arange(n_ep)
+        env.set_episode_table(scenario=(ep * 5) % 32, se_base=(ep % 16) * 24, se_len=24, se_offset=ep % 24,
+                              trf_base=((ep * 5) % 32) * 24, trf_len=24, trf_offset=(ep * 7) % 24)
+        env.set_max_steps(17 + (np.arange(B) % 5) * 6)
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep)
+        env.enable_metrics(8)
+    a, b = _persist_pair(B, se_mode, setup, persist_grid=256, persist_chunk=4)
+    a.env.reset(); b.env.reset()
+    for k in (30, 9, 50, 21):
+        a.env.rollout(k); b.env.rollout(k)
+        torch.cuda.synchronize()
+        _same_state(a, b, (se_mode, k))
+        ma, mb = a.env.episode_metrics(), b.env.episode_metrics()
+        assert torch.equal(ma["episodes_done"], mb["episodes_done"]) and torch.equal(ma["episode_log"], mb["episode_log"])
+    assert int(a.env.episode_metrics()["episodes_done"].min()) >= 2
+    assert b.env.get_option("persist_errors") == 0
+    a.env.close(); b.env.close()

@@ -5,11 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
 B = int(os.environ.get("KPROBE_BATCH", "4096"))
-wl, _ = make_bench_workload(2, torch.device("cuda", 0), batch=B)
+wl, _ = make_bench_workload(int(os.environ.get("KPROBE_CONFIG", "2")), torch.device("cuda", 0), batch=B if "KPROBE_BATCH" in os.environ else None)
+B = wl.env.B
 env = wl.env
-env.set_partitions(int(os.environ.get("KPROBE_PARTS", "3"))); env.reset(); env.rollout(30); torch.cuda.synchronize()
+env.set_partitions(int(os.environ.get("KPROBE_PARTS", "3" if B >= 2048 else "1"))); env.reset(); env.rollout(30); torch.cuda.synchronize()
 for K in (20, 200):
     ts = []
     for _ in range(24 if K == 20 else 6):
         torch.cuda.synchronize(); t0 = time.perf_counter(); env.rollout(K); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f"K={K}: median {np.median(ts) / K * 1e6:.1f} us per TTI (min {min(ts) / K * 1e6:.1f}) = {B * K / np.median(ts) / 1e6:.1f} M env-steps/s", flush=True)
+if env.get_option("persist"):
+    print("persist stats:", {k: env.get_option("persist_stat_" + k) for k in ("keep", "push", "pop", "fresh", "idle_polls")},
+          "errors", env.get_option("persist_errors"), flush=True)
