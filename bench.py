@@ -40,7 +40,8 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ, VALU_CYCLES = 256 * 4, 2.4e9, 4.0   # 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction issues over >= 4 cycles
-PMC_FILE = os.path.join("profiles", "r03_pmc.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_collect.py)
+PMC_FILE = os.path.join("profiles", "r04_pmc.json")   # rocprofv3 --pmc passes of the schedule timed here (tools/profile_rollout.py, pmc_collect_r4.py)
+REFPY_FILE = os.path.join("profiles", "r04_reference_python.json")   # the reference's own Python, timed in the build container
 SAMPLE_S = 0.020                                      # stepping time sampled per timed variant
 
 
@@ -138,9 +139,11 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
     achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9            # per-GPU GB/s on the wall clock
     launch_ms, n_launches = kms["step"], kms["n_launches"]
     ttis_per_launch = kms.get("n_ttis", n_launches) / max(1, n_launches)      # inside a rollout a launch covers several TTIs
-    launch_bytes = alg_bytes / parts * ttis_per_launch
+    env_ttis_per_launch = kms.get("n_env_ttis", batch / parts * kms.get("n_ttis", n_launches)) / max(1, n_launches)
+    launch_bytes = alg_bytes_env_step * env_ttis_per_launch                   # algorithmic bytes of the average launch
     launch_gbs = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    traffic = (pmc or {}).get("stream")
+    traffic = (pmc or {}).get("stream_rollout" if parts > 1 else "stream")
+    moved_per_tti = traffic.get("hbm_bytes_per_tti") if traffic else None      # HBM bytes one TTI of the whole batch moves (counters)
     schedule = (f"ranenv_rollout: the K TTIs of the device policy enqueued in one call, batch stepped as {parts} partitions on "
                 f"{parts} HIP streams, no host between TTIs; a launch of the step kernel takes its partition through "
                 f"{ttis_per_launch:.3g} TTIs on average (up to K/4, at most 10)") if parts > 1 else \
@@ -162,14 +165,21 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
                    "launch": schedule, "se_mode": "stream"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "clock": "wall clock of the timed region (same as value)",
-                     "traffic": traffic.get("hbm_bytes_per_launch") if traffic else None,
-                     "traffic_source": (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, one launch per "
-                                        f"TTI on one stream, {traffic.get('date', 'undated')}; not measured in this run)") if traffic else None,
+                     "frac_algorithmic_bytes": achieved / HBM_PEAK_GBS,
+                     "frac_moved_bytes": (moved_per_tti / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if moved_per_tti else None,
+                     "traffic": (moved_per_tti * env_ttis_per_launch / batch) if moved_per_tti else None,
+                     "traffic_per_tti": moved_per_tti,
+                     "traffic_over_algorithmic": (moved_per_tti / alg_bytes) if moved_per_tti else None,
+                     "traffic_source": (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the launches of THIS schedule -- "
+                                        f"compact steps, {traffic.get('ttis_per_launch_and_partition', 0):.3g} TTIs per launch on average -- summed and "
+                                        f"divided by the TTIs stepped; `traffic` = that per-TTI figure scaled to the env-TTIs of the average launch; "
+                                        f"{traffic.get('date', 'undated')}; not measured in this run)") if traffic else None,
                      "kernel": "ranenv_core_kernel<STEP> (%d concurrent launch(es) of it, %.3g TTIs per launch)" % (parts, ttis_per_launch),
                      "algorithmic_bytes_per_env_step": alg_bytes_env_step,
                      "algorithmic_bytes_per_tti": alg_bytes,
                      "dominant_kernel": {"name": "ranenv_core_kernel<STEP>", "ms": launch_ms, "n_launches": n_launches,
-                                         "envs_per_launch": batch / parts, "ttis_per_launch": ttis_per_launch,
+                                         "envs_per_launch": env_ttis_per_launch / max(1e-9, ttis_per_launch), "ttis_per_launch": ttis_per_launch,
+                                         "env_ttis_per_launch": env_ttis_per_launch,
                                          "algorithmic_bytes": launch_bytes,
                                          "achieved": launch_gbs, "frac": launch_gbs / HBM_PEAK_GBS,
                                          "concurrent_launches": parts,
@@ -189,12 +199,16 @@ def gather_block(env, batch, world, steps, times, kms, parts, pmc):
     t = st["ms_per_step"] * 1e-3
     hbm_frac = b_env * batch / t / (HBM_PEAK_GBS * 1e9)
     out = dict(st)
+    persist = env.get_option("persist")
     out.update({"bytes_per_env_step": b_env,
                 "bytes_model": "4*R (allocated RBs, each read once) + 8*U (sidecar row of per-UE mean SE) + 180*U + S*(85+8*Us) + 4",
-                "hbm_frac": hbm_frac, "kernel": "ranenv_core_kernel_gather<STEP>",
+                "hbm_frac": hbm_frac,
+                "kernel": "ranenv_persist_kernel<gather> (one persistent work-queue launch per workgroup class and rollout call)"
+                          if (persist == 1 or (persist < 0 and batch > 2048)) else "ranenv_core_kernel_gather<STEP>",
+                "env_ttis_per_launch": kms.get("n_env_ttis", 0) / max(1, kms["n_launches"]),
                 "dominant_kernel_ms": kms["step"], "n_launches": kms["n_launches"],
                 "ttis_per_launch": kms.get("n_ttis", kms["n_launches"]) / max(1, kms["n_launches"]), "concurrent_launches": parts})
-    g = (pmc or {}).get("gather")
+    g = (pmc or {}).get("gather_rollout") or (pmc or {}).get("gather")
     if g and g.get("valu_insts_per_launch"):
         issue_s = g["valu_insts_per_launch"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ)
         out.update({"valu_insts_per_tti": g["valu_insts_per_launch"], "issue_bound_s": issue_s, "issue_frac": issue_s / t,
@@ -374,7 +388,7 @@ def main():
         try:
             pj = json.load(open(os.path.join(REPO, PMC_FILE)))
             if pj.get("batch") == batch and pj.get("config") == args.config:
-                pmc = {m: dict(pj[m], date=pj.get("date")) for m in ("stream", "gather") if m in pj}
+                pmc = {m: dict(pj[m], date=pj.get("date")) for m in ("stream", "gather", "stream_rollout", "gather_rollout") if m in pj}
         except Exception:
             pmc = None
 
@@ -405,6 +419,16 @@ def main():
             line["config"]["se_mode"] = "gather (profiling aid: value and roofline are the gather mode's, not the headline)"
         if world == 1 and not args.no_cpu_baseline and not args.only_gather:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_envs, args.cpu_steps)
+            try:      # the reference's own Python for a full step: it never travels, so it is a recorded figure (tools/time_reference_python.py)
+                rp = json.load(open(os.path.join(REPO, REFPY_FILE)))
+                size = "scaled" if (env.S, env.U) == (10, 100) else ("native" if (env.S, env.U) == (5, 25) else None)
+                if size:
+                    line["cpu_baseline"]["reference_python"] = dict(
+                        rp["summary"][size], unit="env-steps/s", size=size, cpu=rp.get("cpu"), cores_visible=rp.get("cores_visible"),
+                        where="measured in the build container, not on the GPU box (the reference does not travel); "
+                              "not measured in this run", what=rp.get("what"), source=REFPY_FILE)
+            except Exception:
+                pass
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

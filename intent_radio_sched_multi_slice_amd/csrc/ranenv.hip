@@ -137,7 +137,8 @@ enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 12 };
 // Work queue of the persistent rollout, one set per workgroup class (hot words on lines of their own).
 struct PersistCtl {
     unsigned fresh[8][32];            // [x][0]: cursor into shard x of the class's env list (entries x, x + 8, x + 16, ...)
-    int remaining; int pad0[31];      // envs of the class that have not finished this launch's TTIs
+    int spare; int pad0[31];
+    unsigned exited; unsigned pad5[31];   // workgroups of this launch that have left: the last one resets the cursors for the next launch
     int abort; int pad1[31];          // a wait gave up: every workgroup leaves
     struct { unsigned head; unsigned pad2[31]; unsigned tail; unsigned pad3[31]; int avail; int pad4[31]; } q[8];   // ready queue of XCD x: head / tail tickets (monotonic), entries committed and not yet claimed
     unsigned long long stat[8][16];   // per XCD (a line each): [0] chunks kept, [1] pushes, [2] pops, [3] fresh takes, [4] polls that found nothing
@@ -179,6 +180,7 @@ struct KP {
     // persistent rollout (ranenv_persist_kernel): this launch's workgroup class
     const int32_t *p_list;            // the class's envs
     int p_count, p_chunk;             // how many; TTIs of an env between two visits of the work queue
+    int p_stagger;                    // one-chunk launches: workgroups start spread over this many steps of ~1.7 us (0 = together)
     struct PersistCtl *p_ctl;         // the class's counters and per-XCD queue heads
     unsigned long long *p_slots;      // [8][p_cap] queue entries {index + 1, item}
     int p_cap;                        // entries per queue (a power of two >= the batch)
@@ -599,8 +601,8 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
 
 #if RANENV_DIAG == 9   /* diagnostic build: s_memtime (100 MHz) of thread 0 at up to S phase boundaries of the step
                           kernel, dumped into policy_scores[e][k] instead of the scores (tools/stamps.py) */
-#define RANENV_STAMP(k) do { if (threadIdx.x == 0 && (k) < p.S) \
-    ST_policy_scores(p)[(size_t)e * p.S + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define RANENV_STAMP(k) do { if (!PERSIST && threadIdx.x == 0 && (k) < p.S) \
+    ST_policy_scores(p)[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define RANENV_STAMP(k) do { } while (0)
 #endif
@@ -901,12 +903,13 @@ struct StepCarry {
 };
 
 template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, typename P>
-DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)   // warm: `cy` holds what the previous TTI of this launch left
+DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,   // warm: `cy` holds what the previous TTI of this launch left
+                     SeStream<GATHER ? 1 : NQ> *se_carry = nullptr, const bool se_ready = false, const bool se_next = false)
 {                                     // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     __shared__ SharedCore<NP> sh;
     auto &xr = sh.xr;
-    int e_ = e_in, tid_ = threadIdx.x;      // e_in: p.e0 + blockIdx.x, or the env a persistent workgroup took from its queue
+    int e_ = __builtin_amdgcn_readfirstlane(e_in), tid_ = threadIdx.x;      // e_in: p.e0 + blockIdx.x, or the env a persistent workgroup took from its queue
     // (opaque to the optimiser: inside step_loop nothing derived from them is carried from one TTI to the next in registers)
     asm volatile("" : "+s"(e_));
     asm volatile("" : "+v"(tid_));
@@ -949,7 +952,12 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
         se_pos = (MODE == MODE_RESET) ? ep.se_offset : uni(ST_se_pos(p)[e]);
         trf_pos = (MODE == MODE_RESET) ? ep.trf_offset : uni(ST_trf_pos(p)[e]);
     } else {
-        ep = cy.ep; t = cy.t; hlen = cy.hlen; npush = cy.npush; se_pos = cy.se_pos; trf_pos = cy.trf_pos;
+        // (wave-uniform by construction; the readfirstlane costs nothing where the compiler already holds the value in an SGPR and
+        // keeps the scalar uses below legal where its divergence analysis gave up on a value carried around the persistent loops)
+        ep.scenario = uni(cy.ep.scenario); ep.se_offset = uni(cy.ep.se_offset); ep.trf_offset = uni(cy.ep.trf_offset);
+        ep.se_len = uni(cy.ep.se_len); ep.trf_len = uni(cy.ep.trf_len); ep.reserved = 0;
+        ep.se_base = uni64(cy.ep.se_base); ep.trf_base = uni64(cy.ep.trf_base);
+        t = uni(cy.t); hlen = uni(cy.hlen); npush = uni(cy.npush); se_pos = uni(cy.se_pos); trf_pos = uni(cy.trf_pos);
     }
     const int sc = ep.scenario;
     se_pos = se_pos < ep.se_len ? se_pos : 0;
@@ -997,8 +1005,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
 #define UE4(f) row_at(ST_##f(p), er4, u4)
 #define UE8(f) row_at(ST_##f(p), er8, u8)
     // window pushes of this env so far (wraps; only differences are used); index of the first push behind the last clearing
-    const int ptot = warm ? cy.ptot : uni(ST_push_total(p)[e]);
-    const int cmark = warm ? cy.cmark : uni(ST_clear_mark(p)[e]);
+    const int ptot = uni(warm ? cy.ptot : ST_push_total(p)[e]);
+    const int cmark = uni(warm ? cy.cmark : ST_clear_mark(p)[e]);
     int lastp = ptot;                               // index behind this UE's last push
     int total = 0, front = 0, front_rem = 0, fifo = 0, rb_start = 0, rb_count = 0;
     long long sum_age = 0, win_sent = 0, win_drop = 0;
@@ -1025,9 +1033,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
             traffic = p.traffic_bits ? row_at(p.traffic_bits, er8, u8)
                                      : (double)row_at(p.trf_pool, ((size_t)ep.trf_base + (size_t)trf_pos) * U * 4, u4);
     };
-#if !RANENV_DEFER_STATE
-    rest_of_state();
-#endif
+    // When the rest of the UE's state is requested: behind the stream by default (see RANENV_DEFER_STATE: registers), but at
+    // entry in the build that has registers to spare (the whole-row queue of a batch at <= 2 waves per SIMD): there its round
+    // trip -- 1.5-2 us of every chain when exposed -- runs under the allocation and the stream.
+    constexpr int DEFER = (!GATHER && NQ >= 8) ? 0 : RANENV_DEFER_STATE;
+    if constexpr (DEFER == 0) rest_of_state();
     if (MODE == MODE_STEP && !warm) sem_prev = UE8(se_mean);
     double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
     if (GATHER) sem_tile = row_at(p.se_mean_pool, (size_t)tile_no * U * 8, u8);
@@ -1054,10 +1064,16 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
         if (tid < S) row_at(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
 #endif
     }
-    const int episode_no = warm ? cy.episode_no : (gen_traffic ? uni(ST_episode_no(p)[e]) : 0);
+    const int episode_no = warm ? uni(cy.episode_no) : (gen_traffic ? uni(ST_episode_no(p)[e]) : 0);
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
-    SeStream<GATHER ? 1 : NQ> se1;
-    if (!GATHER) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
+    // SE_AHEAD (the whole-row build of a batch at <= 2 waves per SIMD): the queue lives in the caller's loop, and a TTI that is
+    // followed by another one of the same env requests that TTI's tile before its own observation tail (below): the loads are
+    // in flight through the tail, the next entry and the next allocation -- ~8 us of the chain -- and the stream phase finds them
+    // landed.  The registers are there (2 waves per SIMD: 256 VGPRs), nothing else of the chain depends on the tile.
+    constexpr bool SE_AHEAD = PERSIST && !GATHER && MODE == MODE_STEP && NQ >= 8;
+    SeStream<GATHER ? 1 : NQ> se_local;
+    SeStream<GATHER ? 1 : NQ> &se1 = SE_AHEAD ? *se_carry : se_local;
+    if (!GATHER && !(SE_AHEAD && se_ready)) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables.
     // A warm TTI finds both as it needs them: the tables are the scenario's, and every role writes a slice's rows at its
@@ -1087,9 +1103,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
     // ---- (1) SE row sums -------------------------------------------------------------------------
     double my_full = 0.0, my_part = 0.0;
     auto hook = [&]() {
-#if RANENV_DEFER_STATE == 1
-        rest_of_state();
-#endif
+        if constexpr (DEFER == 1) rest_of_state();
     };
     if constexpr (GATHER) {
 #if RANENV_GATHER_STATE_FIRST
@@ -1111,10 +1125,10 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
     } else {
         row_sums(se1, R, [](int) { return false; }, my_full, my_part, hook);
     }
-#if RANENV_DEFER_STATE == 2
-    if (!(GATHER && RANENV_GATHER_STATE_FIRST))
-        rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
-#endif
+    if constexpr (DEFER == 2) {
+        if (!(GATHER && RANENV_GATHER_STATE_FIRST))
+            rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
+    }
     RANENV_STAMP(3);
     wg_sync();        // every thread is done with the allocation's use of the per-slice rows
     RANENV_STAMP(4);
@@ -1328,6 +1342,14 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in)
         if ((tid & (WAVE - 1)) == 0) { acc_add(COLD(acc) + (size_t)e * 8 + 6, ws); acc_add(COLD(acc) + (size_t)e * 8 + 7, wd); }
     }
     RANENV_STAMP(5);
+    if constexpr (SE_AHEAD) {
+        if (se_next) {         // the next TTI's tile of this env (the position it will derive itself: cy.se_pos below)
+            const int pos_next = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
+            asm volatile("" ::: "memory");           // (behind this TTI's state stores in program order: they need no register)
+            se1.init(p.se_pool + (size_t)(ep.se_base + (long long)pos_next) * (size_t)p.se_stride, U, u, R);
+            asm volatile("" ::: "memory");
+        }
+    }
     wg_sync();
     RANENV_STAMP(6);
     do {
@@ -1693,7 +1715,7 @@ template <typename P> DEVFN int persist_pull(const P &p, PersistLocal &pl)
 template <typename P> DEVFN int persist_finish(const P &p, PersistLocal &pl, int e, int done, int n_tti)
 {
     PersistCtl *c = p.p_ctl;
-    if (done >= n_tti) { __hip_atomic_fetch_add(&c->remaining, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+    if (done >= n_tti) return 0;
     if (pq_ldi(&c->abort) != 0) return 0;
     const int fresh = persist_try_fresh(p, pl);
     if (fresh == PERSIST_NONE) {
@@ -1722,6 +1744,20 @@ DEVFN void persist_loop()
         pl.xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);      // HW_REG_XCC_ID, bits 3:0
     }
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    {
+        // A launch whose workgroups all keep their env for good (one chunk: a batch far below what the chip holds) starts them
+        // spread over about one TTI instead of together: in lock step every workgroup streams its SE tile at the same moment --
+        // 55 MB in one burst, then HBM idles while everybody allocates -- and the stream phase of every chain is as long as that
+        // burst takes.  Out of step a chain's stream phase is one memory latency.  (The workgroups do not meet again: nothing
+        // synchronises them.)
+        kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kc));
+        const int stagger = kc->p_stagger;
+        if (stagger > 0) {
+            const int k = (int)((((unsigned)blockIdx.x * 0x9E3779B1u) >> 20) % (unsigned)stagger);
+            for (int i = 0; i < k; i++) __builtin_amdgcn_s_sleep(64);          // ~1.7 us each
+        }
+    }
     for (;;) {
         {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1730,11 +1766,26 @@ DEVFN void persist_loop()
         }
         __syncthreads();
         const int item = uni(pl.item);
-        if (item < 0) return;
+        if (item < 0) {
+            // the last workgroup out resets what the next launch of this class starts from (nobody is left to read the cursors;
+            // the queue tickets are monotonic and stay)
+            if (tid0 == 0) {
+                kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kc));
+                PersistCtl *c = kc->p_ctl;
+                const unsigned n = __hip_atomic_fetch_add(&c->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n + 1u == gridDim.x) {
+                    for (int x = 0; x < 8; x++) __hip_atomic_store(&c->fresh[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&c->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            return;
+        }
         const int e = item & ((1 << PERSIST_ENV_BITS) - 1);
         int done = (int)((unsigned)item >> PERSIST_ENV_BITS);
         StepCarry cy = {};
-        bool warm = false;
+        SeStream<GATHER ? 1 : NQ> seq;               // (the whole-row build requests a TTI's tile one TTI ahead: step_body, SE_AHEAD)
+        bool warm = false, se_ready = false;
         for (;;) {                                   // chunks of this env for as long as nobody is waiting
             kp_const_t kc0 = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc0));
@@ -1742,12 +1793,14 @@ DEVFN void persist_loop()
             // (an env's first chunk is 1..chunk TTIs long by a hash of its index: the workgroups of a launch start together, and
             // chunks of one length would bring all of them to the queues at the same moments)
             int want = kc0->p_chunk;
-            if (done == 0 && want > 1) want = 1 + (int)((((unsigned)e * 0x9E3779B1u) >> 16) % (unsigned)want);
+            if (done == 0 && want > 1 && want < n_tti) want = 1 + (int)((((unsigned)e * 0x9E3779B1u) >> 16) % (unsigned)want);
             const int n = left < want ? left : want;
             for (int k = 0; k < n; k++) {
                 kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kc));
-                (void)step_body<MODE_STEP, NQ, GATHER, NP, true>(*kc, cy, warm, e);
+                const bool ahead = RANENV_WARM_ENTRY != 0 && k + 1 < n;       // the next TTI of this chunk enters warm
+                (void)step_body<MODE_STEP, NQ, GATHER, NP, true>(*kc, cy, warm, e, &seq, se_ready, ahead);
+                se_ready = ahead;
                 if (k + 1 < n) { warm = RANENV_WARM_ENTRY != 0; if (warm) wg_sync(); else __syncthreads(); }
             }
             done += n;
@@ -1764,34 +1817,46 @@ DEVFN void persist_loop()
     }
 }
 
+#ifndef RANENV_PERSIST_WAVES_PER_EU
+#define RANENV_PERSIST_WAVES_PER_EU 5
+#endif
 template <bool GATHER, int NP>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(5, 5))) ranenv_persist_kernel(const KP p)
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_PERSIST_WAVES_PER_EU, RANENV_PERSIST_WAVES_PER_EU))) ranenv_persist_kernel(const KP p)
 {
     (void)p;                                         // (read in place, like step_loop)
+#if RANENV_DIAG == 0                                 /* (the diagnostic / ablation builds run the launch-per-chunk rollout only) */
     persist_loop<GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP>();
+#endif
+}
+
+// The same for a batch that leaves the chip at <= 2 waves per SIMD (BASELINE configs[1], B 1024): 256 VGPRs are there for the
+// taking, so a lane keeps its whole SE row in flight (16 groups of 8 loads): the stream phase of a workgroup's chain is one
+// memory latency instead of four (profiles/r04_ab_log.txt: 23.4 against 26.6 us per TTI).  Streaming only.
+#ifndef RANENV_SE_DEPTH_TINY
+#define RANENV_SE_DEPTH_TINY 16
+#endif
+template <int NP>
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ranenv_persist_kernel_tiny(const KP p)
+{
+    (void)p;
+#if RANENV_DIAG == 0
+    persist_loop<RANENV_SE_DEPTH_TINY, false, NP>();
+#endif
 }
 
 // Sort the envs by the waves a compact step of theirs needs: class c = ceil(slice members of the env's scenario / 64) - 1.
 __global__ void __launch_bounds__(256) ranenv_persist_classify_kernel(const ranenv_episode *eps, const int32_t *members, int B, int n_class,
-                                                                      int32_t *list, int32_t *count)
+                                                                      int one_class, int32_t *list, int32_t *count)
 {
     const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (e >= B) return;
     const int m = members[eps[e].scenario];
     int c = m <= 0 ? 0 : (m + WAVE - 1) / WAVE - 1;
     c = c < n_class ? c : n_class - 1;
+    if (one_class) c = n_class - 1;               // a batch far below what the chip holds: idle waves cost nothing, a second launch does
     const int pos = atomicAdd(&count[c], 1);
     list[(size_t)c * B + pos] = e;
 }
-// Per launch: the class's cursors and its count of unfinished envs (queue heads and tails are monotonic: never reset).
-__global__ void __launch_bounds__(64) ranenv_persist_prep_kernel(PersistCtl *ctl, const int32_t *count, int n_class)
-{
-    const int c = (int)blockIdx.x, t = (int)threadIdx.x;
-    if (c >= n_class) return;
-    if (t < 8) ctl[c].fresh[t][0] = 0u;
-    if (t == 8) { ctl[c].remaining = count[c]; ctl[c].abort = 0; }
-}
-
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
 // 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 16 SE loads in flight per lane (8 until the build stopped hoisting
 // at machine level, which freed the registers for the second group) -- occupancy hides more latency than a still deeper
@@ -1812,8 +1877,11 @@ __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(c
 {
     step_loop<MODE, (MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP, MANY>(p);
 }
+#ifndef RANENV_SMALL_WAVES_PER_EU
+#define RANENV_SMALL_WAVES_PER_EU 4
+#endif
 template <int MODE, int NP, bool MANY>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_SMALL_WAVES_PER_EU, RANENV_SMALL_WAVES_PER_EU))) ranenv_core_kernel_small(const KP p)
 {
     step_loop<MODE, RANENV_SE_DEPTH_SMALL, false, NP, MANY>(p);
 }
@@ -2160,8 +2228,10 @@ struct ranenv {
     // compact steps (KP::compact): allowed while UEs outside every slice provably receive no traffic
     int persist = -1;              // ranenv_rollout as one persistent work-queue launch per workgroup class (option "persist"):
                                    // 0 never, 1 whenever possible, -1 (default) where it was measured to win: SE gather mode with a
-                                   // batch that fills the CUs
+                                   // batch that fills the CUs, and either mode with a batch of <= 2 waves per SIMD
     int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
+    int n_cus = 256;               // compute units of the device (ranenv_create)
+    int persist_stagger = 0;       // one-chunk persistent launches: start spread, in steps of ~1.7 us (see persist_loop)
     int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
@@ -2488,6 +2558,13 @@ hipError_t ensure_streams(ranenv_handle h, size_t n)      // handle-owned stream
     return hipSuccess;
 }
 
+// A batch whose widest blocks all together stay within 2 waves per SIMD (8 per CU): one class, and -- streaming -- the build
+// with the whole SE row in flight.
+bool persist_tiny(ranenv_handle h)
+{
+    return (long long)h->cfg.batch * (h->nt / WAVE) <= 8ll * h->n_cus;
+}
+
 template <bool GATHER>
 const void *persist_kernel_of(int np)
 {
@@ -2532,7 +2609,7 @@ int persist_prepare(ranenv_handle h, hipStream_t stream)
     if (h->pclass_dirty) {
         HIP_TRY(h, hipMemsetAsync(h->d_pcount, 0, sizeof(int32_t) * (size_t)NC, stream));
         hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes,
-                           h->d_members, B, NC, h->d_plist, h->d_pcount);
+                           h->d_members, B, NC, persist_tiny(h) ? 1 : 0, h->d_plist, h->d_pcount);
         HIP_TRY(h, hipMemcpyAsync(h->pcount_host.data(), h->d_pcount, sizeof(int32_t) * (size_t)NC, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));
         h->pclass_dirty = false;
@@ -2547,12 +2624,13 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
 {
     const int B = h->cfg.batch, NC = h->p_nclass;
     const bool gather = h->se_mode == RANENV_SE_GATHER;
-    kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0;
+    kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0; kp.p_stagger = 0;
     kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->d_perr;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
         kp.se_mean_pool = h->d_se_mean; kp.se_rp = h->se_rp;
     }
+    const bool tiny = persist_tiny(h);            // (then every env is in the widest class and the grid is the batch)
     int &slots_cu = h->p_wave_slots[gather ? 1 : 0];
     if (slots_cu == 0) {
         int nb = 0;
@@ -2560,17 +2638,13 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, WAVE, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 16; }
         slots_cu = nb;
     }
-    hipDeviceProp_t prop;
-    int cus = 256;
-    if (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    long long W = (long long)slots_cu * cus, demand = 0;
+    long long W = (long long)slots_cu * h->n_cus, demand = 0;
     if (h->persist_grid > 0 && h->persist_grid < W) W = h->persist_grid;
     int n_used = 0;
     for (int c = 0; c < NC; c++) { demand += (long long)h->pcount_host[(size_t)c] * (c + 1); n_used += h->pcount_host[(size_t)c] > 0 ? 1 : 0; }
     if (demand == 0) return RANENV_OK;
     hipError_t e = ensure_streams(h, (size_t)(n_used > 1 ? n_used : 1));
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout, streams: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(ranenv_persist_prep_kernel, dim3((unsigned)NC), dim3(64), 0, stream, h->d_pctl, h->d_pcount, NC);
     if (n_used > 1) HIP_TRY(h, hipEventRecord(h->ev_in, stream));
     int k = 0;                                     // stream index: 0 = the caller's
     for (int c = NC - 1; c >= 0; c--) {
@@ -2582,6 +2656,9 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         hipStream_t s = k == 0 ? stream : h->part_stream[(size_t)k];
         if (k > 0) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_in, 0));
         KP kc = kp;
+        // (every env of the class has a workgroup of its own and all of them are resident: nobody can ever be waiting, so the
+        // launch is one chunk -- no looks at the queues, no staggered first chunk)
+        if (tiny && g == n) { kc.p_chunk = n_tti > 1 ? n_tti : 1; kc.p_stagger = n_tti >= 8 ? h->persist_stagger : 0; }
         kc.p_list = h->d_plist + (size_t)c * B; kc.p_count = n; kc.p_ctl = h->d_pctl + c;
         kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2596,6 +2673,13 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         }
         const dim3 grid((unsigned)g), block((unsigned)((c + 1) * WAVE));
         if (gather) launch_persist<true>(h->np, kc, grid, block, s, ev0, ev1);
+        else if (tiny) {
+            switch (h->np) {
+            case 8: if (ev0) hipExtLaunchKernelGGL((ranenv_persist_kernel_tiny<8>), grid, block, 0, s, ev0, ev1, 0, kc); else hipLaunchKernelGGL((ranenv_persist_kernel_tiny<8>), grid, block, 0, s, kc); break;
+            case 10: if (ev0) hipExtLaunchKernelGGL((ranenv_persist_kernel_tiny<10>), grid, block, 0, s, ev0, ev1, 0, kc); else hipLaunchKernelGGL((ranenv_persist_kernel_tiny<10>), grid, block, 0, s, kc); break;
+            default: if (ev0) hipExtLaunchKernelGGL((ranenv_persist_kernel_tiny<16>), grid, block, 0, s, ev0, ev1, 0, kc); else hipLaunchKernelGGL((ranenv_persist_kernel_tiny<16>), grid, block, 0, s, kc); break;
+            }
+        }
         else launch_persist<false>(h->np, kc, grid, block, s, ev0, ev1);
         if (k > 0) HIP_TRY(h, hipEventRecord(h->part_done[(size_t)k], s));
         k++;
@@ -2627,6 +2711,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist") { h->persist = v < 0 ? -1 : (v != 0 ? 1 : 0); return RANENV_OK; }
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
+    if (k == "persist_stagger") { h->persist_stagger = v < 0 ? 0 : (v > 64 ? 64 : (int)v); return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -2638,7 +2723,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid"};
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid", "persist_stagger"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -2728,8 +2813,10 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     {   // fail at create, not at the first step, when the code object has no gfx950 image
         hipFuncAttributes fa;
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) {
+            h->n_cus = prop.multiProcessorCount;
             h->small_batch = (long long)cfg->batch <= 8ll * prop.multiProcessorCount;
+        }
         e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&ranenv_core_kernel<MODE_STEP, 16, false>));
         if (e != hipSuccess) {
             ranenv_destroy(h);
@@ -2759,6 +2846,7 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "persist") *value = h->persist;
     else if (k == "persist_chunk") *value = h->persist_chunk;
     else if (k == "persist_grid") *value = h->persist_grid;
+    else if (k == "persist_stagger") *value = h->persist_stagger;
     else if (k.rfind("persist_stat_", 0) == 0) {      // keep / push / pop / fresh / idle_polls, summed over classes and XCDs
         static const char *const names[] = {"keep", "push", "pop", "fresh", "idle_polls"};
         int which = -1;
@@ -3254,7 +3342,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    const bool persist_wanted = h->persist == 1 || (h->persist < 0 && h->se_mode == RANENV_SE_GATHER && !h->small_batch);
+    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && (h->se_mode == RANENV_SE_GATHER ? (!h->small_batch || persist_tiny(h)) : persist_tiny(h))));
     if (persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0) {
         for (int done_ttis = 0; done_ttis < n_steps;) {
             int n_tti = n_steps - done_ttis;

@@ -57,6 +57,7 @@ def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
     monkeypatch.delenv("RANENV_FUSE", raising=False)          # (the default policy, whatever knob the suite runs under)
     monkeypatch.delenv("RANENV_FUSE_FIRST", raising=False)
     a = _bench_like(96, False)
+    a.env.set_option("persist", 0)                            # (a batch this small would run as one persistent launch: below)
     a.env.reset(); a.env.set_partitions(3)
     # first launches of 10 / 6 / 1 TTIs (partition 0 / 1 / 2), then 10s: 10+10+10+10, 6+10+10+10+4, 1+10+10+10+9
     a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
@@ -65,9 +66,14 @@ def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
     assert (pa["n_launches"], pa["n_ttis"]) == (16, 69)
     a.env.profile_begin(); a.env.step(); pa = a.env.profile_end()
     assert (pa["n_launches"], pa["n_ttis"]) == (3, 3)
+    # the persistent rollout: one launch for all 40 TTIs of all 96 envs (a batch far below what the chip holds is one class)
+    a.env.set_option("persist", -1)
+    a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
+    assert (pa["n_launches"], pa["n_ttis"], pa["n_env_ttis"]) == (1, 40, 96 * 40)
     a.env.close()
     monkeypatch.setenv("RANENV_FUSE", "1")
     b = _bench_like(96, False)
+    b.env.set_option("persist", 0)
     b.env.reset(); b.env.set_partitions(3)
     b.env.profile_begin(); b.env.rollout(40); pb = b.env.profile_end()
     assert (pb["n_launches"], pb["n_ttis"]) == (120, 120)
