@@ -158,7 +158,7 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
         "repeats": st["repeats"], "value_min": st["value_min"], "value_max": st["value_max"],
         "timing": f"blocks of exactly {args.steps} steps, each between barrier + device sync (MAX over ranks); value = median of "
                   f"{st['repeats']} blocks",
-        "config": {"workload": f"BASELINE.json configs[{args.config}]: {label}; batch {batch} per GPU; SE replayed from "
+        "config": {"workload": (f"BASELINE.json configs[{args.config}]" if args.config != 5 else "NOT a BASELINE config") + f": {label}; batch {batch} per GPU; SE replayed from "
                                f"an HBM pool of {args.traces}x{args.trace_len} float32 tiles{workload_extra}",
                    "batch_per_gpu": batch, "global_batch": batch * world, "n_slices": S, "n_ues": U,
                    "n_rbs": R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only",
@@ -226,9 +226,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="envs per GPU (default: the config's own)")
-    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4),
+    ap.add_argument("--config", default="2", choices=("1", "2", "3", "4", "native"),
                     help="BASELINE.json configs index: 1 = B1024 MARR+RR, 2 = B4096 MAPF+PF (default; 3 = the same "
-                         "per GPU, i.e. what --gpus 8 runs), 4 = mult_slice_seq sweep B8192, mixed masks")
+                         "per GPU, i.e. what --gpus 8 runs), 4 = mult_slice_seq sweep B8192, mixed masks; native = the "
+                         "reference's own size (S 5 / U 25 / 27 RBGs of 5), B 16384, MAPF+PF: not a BASELINE config")
     ap.add_argument("--traces", type=int, default=200)
     ap.add_argument("--trace-len", type=int, default=1000,
                     help="TTIs per channel trace (1000 = a whole episode: no env ever replays a tile; the pool is "
@@ -252,6 +253,8 @@ def main():
                     help="plumbing rehearsal of a multi-rank launch on a box with ONE GPU: every rank uses cuda:0 and the process "
                          "group is gloo (RCCL refuses two ranks on one device); the line is labelled a rehearsal, not a measurement")
     args = ap.parse_args()
+    args.config_name = args.config
+    args.config = 5 if args.config == "native" else int(args.config)
 
     import torch
     import torch.distributed as dist

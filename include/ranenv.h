@@ -267,6 +267,15 @@ int ranenv_get_part_stream(ranenv_handle h, int32_t part, void **stream);
  *                               ranenv_bind_se_pool falls back to STREAM.  Steps with explicit dev_se_tiles and
  *                               ranenv_step_dense keep streaming. */
 int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream);
+/* Gather-only ingest (channels/quadriga.py:56-76 for a handle that will only ever run the gather mode): builds both sidecars
+ * straight from QuaDRiGa received power -- float64 [n_tiles][R][U], RB-major like the .mat -- and switches the handle to
+ * RANENV_SE_GATHER; no RB-major float32 pool exists or is needed (footprint per tile U * (8 + 4 * roundup(R, 8)) bytes instead of
+ * that plus U * R * 4).  The sidecars are bit for bit what ranenv_se_from_power + ranenv_bind_se_pool + ranenv_set_se_mode(GATHER)
+ * build.  Afterwards: reset / step / step_range / step_part / rollout / auto-reset replay pooled tiles through the sidecars;
+ * steps with explicit dev_se_tiles stream those; ranenv_step_dense needs explicit tiles; ranenv_set_se_mode(STREAM) fails until a
+ * pool is bound (ranenv_bind_se_pool, which drops the gather mode as always).  The power array may be freed when the call returns. */
+int ranenv_bind_se_gather_from_power(ranenv_handle h, const double *dev_power, int64_t n_tiles, double tx_power_per_rb,
+                                     double noise_power, void *stream);
 /* Diagnostic: the gather mode's sidecars: row_mean [n_tiles][U] float64, ue_major [n_tiles][U][row_floats] float32. */
 int ranenv_get_se_sidecars(ranenv_handle h, double **dev_row_mean, float **dev_ue_major, int32_t *row_floats);
 

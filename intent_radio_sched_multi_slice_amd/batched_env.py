@@ -176,12 +176,29 @@ class BatchedRanEnv:
                         "ranenv_set_se_mode")
         self.se_mode = mode
 
+    def bind_se_gather_from_power(self, power: torch.Tensor, transmission_power: float = 100.0,
+                                  thermal_noise_power: float = 10e-14):
+        """Gather-only channel ingest (channels/quadriga.py:56-76): QuaDRiGa received power, float64 [n_tiles, R, U] on this GPU
+        (the .mat's own RB-major order), straight into the gather mode's sidecars -- no RB-major float32 pool is built or kept.
+        Same sidecars bit for bit as ``bind_se_pool(quadriga_pool_from_power(power, R))`` + ``set_se_mode("gather")``."""
+        if power.dtype != torch.float64 or power.device != self.device or power.dim() != 3 or tuple(power.shape[1:]) != (self.R, self.U):
+            raise RanEnvError(f"power must be a float64 [n_tiles, R={self.R}, U={self.U}] tensor on {self.device}")
+        power = power.contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.ranenv_bind_se_gather_from_power(self._h, _ptr(power), power.shape[0],
+                                                                  float(transmission_power) / float(self.R),
+                                                                  float(thermal_noise_power), self._stream()),
+                        "ranenv_bind_se_gather_from_power")
+        self._keep.pop("se_pool", None)
+        self._n_se_tiles = int(power.shape[0])
+        self.se_mode = "gather"
+
     def se_sidecars(self) -> Dict[str, torch.Tensor]:
         """Diagnostic: the gather mode's sidecars, zero copy: ``row_mean`` float64 [tiles, U], ``ue_major`` float32
         [tiles, U, roundup(R, 8)]."""
         mean, um, rp = C.c_void_p(), C.c_void_p(), C.c_int32()
         self._check(self._lib.ranenv_get_se_sidecars(self._h, C.byref(mean), C.byref(um), C.byref(rp)), "ranenv_get_se_sidecars")
-        n = self._keep["se_pool"].shape[0]
+        n = self._keep["se_pool"].shape[0] if "se_pool" in self._keep else self._n_se_tiles
         return {"row_mean": torch.as_tensor(_DevArray(mean.value, (n, self.U), "f8", self), device=self.device),
                 "ue_major": torch.as_tensor(_DevArray(um.value, (n, self.U, rp.value), "f4", self), device=self.device)}
 

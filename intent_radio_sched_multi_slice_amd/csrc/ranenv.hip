@@ -1821,7 +1821,7 @@ DEVFN void persist_loop()
 #define RANENV_PERSIST_WAVES_PER_EU 5
 #endif
 template <bool GATHER, int NP>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_PERSIST_WAVES_PER_EU, RANENV_PERSIST_WAVES_PER_EU))) ranenv_persist_kernel(const KP p)
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(NP == 16 ? 4 : RANENV_PERSIST_WAVES_PER_EU, NP == 16 ? 4 : RANENV_PERSIST_WAVES_PER_EU))) ranenv_persist_kernel(const KP p)
 {
     (void)p;                                         // (read in place, like step_loop)
 #if RANENV_DIAG == 0                                 /* (the diagnostic / ablation builds run the launch-per-chunk rollout only) */
@@ -1889,8 +1889,12 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RA
 #ifndef RANENV_GATHER_WAVES_PER_EU
 #define RANENV_GATHER_WAVES_PER_EU 5
 #endif
+// (the 16-wide row build keeps 16-entry rows of doubles alive in the allocation and does not fit 96 registers with the per-TTI loop
+// around it -- 2...10 spilled VGPRs, the only scratch in the library -- so it is built for 4 waves per SIMD: S or Us above 10 is
+// not a BASELINE size, and a spill in every TTI costs more than the fifth wave gains, profiles/r03_ab_log.txt)
+#define RANENV_WPE_NP(w) ((NP == 16 && MANY) ? 4 : (w))
 template <int MODE, int NP, bool MANY>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_GATHER_WAVES_PER_EU, RANENV_GATHER_WAVES_PER_EU)))
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU), RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU))))
 ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP, MANY>(p); }
 // Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
 
@@ -1917,6 +1921,49 @@ __global__ void __launch_bounds__(CORE_NT) ranenv_se_sidecar_kernel(const float 
     for (int i = tid; i < U * Rp; i += (int)blockDim.x) {
         const int uu = i / Rp, r = i - uu * Rp;
         out[i] = r < R ? tile[(size_t)r * U + uu] : 0.0f;
+    }
+}
+
+// Gather-only ingest (ranenv_bind_se_gather_from_power): the same two sidecars straight from QuaDRiGa received power
+// (channels/quadriga.py:56-69), without an RB-major float32 pool ever existing.  The float32 SE of an element is what
+// ranenv_se_from_power would have stored; the mean runs through row_sums over those float32 values, so both sidecars are bit for
+// bit what ranenv_set_se_mode builds from the pool ranenv_se_from_power writes.
+struct PowerStream {           // row_sums' source interface over a tile of float64 power, converted on the way in
+    static constexpr int NSLOT = 2;
+    const double *tile; int U, u, R; double tx, noise;
+    float q[NSLOT][8];
+    DEVFN float se_of(int r) const
+    {
+        const int rr = r < R ? r : R - 1;                              // (padding rows of the last group: never summed)
+        return (float)log2(1.0 + (tx * tile[(size_t)rr * U + u]) / (0.0 + noise));
+    }
+    DEVFN void refill(int d, int r0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) q[d][j] = se_of(r0 + j);
+    }
+    DEVFN void init() { for (int d = 0; d < NSLOT; d++) if (d * 8 < R) refill(d, d * 8); }
+    DEVFN void take(int d, float (&x)[8], int) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = q[d][j];
+    }
+};
+
+__global__ void __launch_bounds__(CORE_NT) ranenv_se_sidecar_from_power_kernel(const double *power, long long tile0, int U, int R, int Rp,
+                                                                               double tx, double noise, double *mean, float *um)
+{
+    const long long t = tile0 + blockIdx.x;
+    const double *tile = power + (size_t)t * (size_t)U * (size_t)R;
+    const int tid = threadIdx.x;
+    PowerStream ps;
+    ps.tile = tile; ps.U = U; ps.u = tid < U ? tid : U - 1; ps.R = R; ps.tx = tx; ps.noise = noise;
+    ps.init();
+    double full = 0.0, part = 0.0;
+    row_sums(ps, R, [](int) { return false; }, full, part, []() {});
+    if (tid < U) mean[(size_t)t * U + tid] = full / (double)R;
+    float *out = um + (size_t)t * (size_t)U * Rp;
+    for (int i = tid; i < U * Rp; i += (int)blockDim.x) {
+        const int uu = i / Rp, r = i - uu * Rp;
+        out[i] = r < R ? (float)log2(1.0 + (tx * tile[(size_t)r * U + uu]) / (0.0 + noise)) : 0.0f;
     }
 }
 
@@ -3038,7 +3085,7 @@ int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *eps, void *stream
         if (e.se_len < 1 || e.se_offset < 0 || e.se_offset >= e.se_len || e.se_base < 0 || e.trf_len < 1 ||
             e.trf_offset < 0 || e.trf_offset >= e.trf_len || e.trf_base < 0)
             return fail(h, RANENV_E_INVALID, "env %d: need len >= 1, 0 <= offset < len, base >= 0", b);
-        if (h->kp.se_pool && e.se_base + e.se_len > h->se_tiles_n)
+        if (h->se_tiles_n > 0 && e.se_base + e.se_len > h->se_tiles_n)
             return fail(h, RANENV_E_INVALID, "env %d: SE trace [%lld,+%d) exceeds the bound pool of %lld tiles", b, (long long)e.se_base, e.se_len, (long long)h->se_tiles_n);
         if (h->kp.trf_pool && e.trf_base + e.trf_len > h->trf_rows_n)
             return fail(h, RANENV_E_INVALID, "env %d: traffic trace [%lld,+%d) exceeds the bound pool of %lld rows", b, (long long)e.trf_base, e.trf_len, (long long)h->trf_rows_n);
@@ -3065,7 +3112,9 @@ static int check_ready(ranenv_handle h, const float *se_tiles, const double *tra
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     if (!h->have_scenarios) return fail(h, RANENV_E_STATE, "no scenarios loaded (ranenv_load_scenarios)");
     if (!h->have_episodes) return fail(h, RANENV_E_STATE, "no episode descriptors (ranenv_set_episodes)");
-    if (!se_tiles && !h->kp.se_pool) return fail(h, RANENV_E_STATE, "no SE tiles given and no SE pool bound");
+    // (a handle whose sidecars came straight from power -- ranenv_bind_se_gather_from_power -- replays tiles without an RB-major pool)
+    if (!se_tiles && !h->kp.se_pool && !(h->se_mode == RANENV_SE_GATHER && h->d_se_mean))
+        return fail(h, RANENV_E_STATE, "no SE tiles given and no SE pool bound");
     if (need_traffic && !traffic_bits && !h->kp.trf_pool && !h->kp.trf_gen)
         return fail(h, RANENV_E_STATE, "no traffic given, no traffic pool bound and no traffic generator set");
     return RANENV_OK;
@@ -3109,6 +3158,7 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     int rc = check_ready(h, se_tiles, traffic_bits, true);
     if (rc != RANENV_OK) return rc;
     if (!dense) return fail(h, RANENV_E_INVALID, "null sched_decision");
+    if (!se_tiles && !h->kp.se_pool) return fail(h, RANENV_E_STATE, "a dense step reads whole SE rows: it needs explicit tiles or an RB-major pool (this handle has gather sidecars only)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     KP kp = h->kp;
     kp.env_mask = nullptr; kp.se_tiles = se_tiles; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = traffic_bits;
@@ -3193,8 +3243,15 @@ int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream_)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     if (mode != RANENV_SE_STREAM && mode != RANENV_SE_GATHER) return fail(h, RANENV_E_INVALID, "unknown SE mode %d", mode);
-    if (mode == RANENV_SE_STREAM) { h->se_mode = RANENV_SE_STREAM; return RANENV_OK; }
-    if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "the SE gather mode needs a bound SE pool (ranenv_bind_se_pool)");
+    if (mode == RANENV_SE_STREAM) {
+        if (!h->kp.se_pool && h->se_mode == RANENV_SE_GATHER)
+            return fail(h, RANENV_E_STATE, "this handle's sidecars came straight from power: there is no RB-major pool to stream (ranenv_bind_se_pool)");
+        h->se_mode = RANENV_SE_STREAM; return RANENV_OK;
+    }
+    if (!h->kp.se_pool) {
+        if (h->d_se_mean && h->se_tiles_n > 0) { h->se_mode = RANENV_SE_GATHER; return RANENV_OK; }      // sidecars straight from power
+        return fail(h, RANENV_E_STATE, "the SE gather mode needs a bound SE pool (ranenv_bind_se_pool) or sidecars from power (ranenv_bind_se_gather_from_power)");
+    }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
     const int U = h->cfg.n_ues, R = h->cfg.n_rbs, Rp = (R + 7) & ~7;
@@ -3228,6 +3285,46 @@ int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream_)
     // device synchronisation also ends with one, instead of an event every partition stream would have to wait for.
     HIP_TRY(h, hipStreamSynchronize(stream));
     h->se_mode = RANENV_SE_GATHER;
+    return RANENV_OK;
+}
+
+int ranenv_bind_se_gather_from_power(ranenv_handle h, const double *dev_power, int64_t n_tiles, double tx_power_per_rb,
+                                     double noise_power, void *stream_)
+{
+    if (!h || !dev_power) return fail(h, RANENV_E_INVALID, "null argument");
+    if (n_tiles < 1) return fail(h, RANENV_E_INVALID, "n_tiles must be >= 1");
+    if (!(noise_power > 0.0)) return fail(h, RANENV_E_INVALID, "noise_power must be positive");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const int U = h->cfg.n_ues, R = h->cfg.n_rbs, Rp = (R + 7) & ~7;
+    const size_t nt = (size_t)n_tiles;
+    auto drop = [&](void *ptr) {
+        if (!ptr) return;
+        for (size_t i = 0; i < h->allocs.size(); i++) if (h->allocs[i] == ptr) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+        (void)hipFree(ptr);
+    };
+    HIP_TRY(h, hipDeviceSynchronize());
+    drop(h->d_se_mean); drop(h->d_se_um); h->d_se_mean = nullptr; h->d_se_um = nullptr;
+    void *pm = nullptr, *pu = nullptr;
+    hipError_t e = hipMalloc(&pm, nt * (size_t)U * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&pu, nt * (size_t)U * (size_t)Rp * sizeof(float));
+    if (e != hipSuccess) {
+        if (pm) (void)hipFree(pm);
+        return fail(h, RANENV_E_NOMEM, "SE gather sidecars (%zu tiles: %.2f GB): %s", nt, (double)(nt * (size_t)U * (8 + 4 * (size_t)Rp)) / 1e9, hipGetErrorString(e));
+    }
+    h->allocs.push_back(pm); h->allocs.push_back(pu);
+    h->d_se_mean = (double *)pm; h->d_se_um = (float *)pu; h->se_rp = Rp;
+    for (size_t t0 = 0; t0 < nt; t0 += 1u << 20) {
+        const size_t n = nt - t0 < (1u << 20) ? nt - t0 : (1u << 20);
+        hipLaunchKernelGGL(ranenv_se_sidecar_from_power_kernel, dim3((unsigned)n), dim3((unsigned)h->nt), 0, stream, dev_power, (long long)t0,
+                           U, R, Rp, tx_power_per_rb, noise_power, h->d_se_mean, h->d_se_um);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, RANENV_E_HIP, "SE sidecar-from-power launch: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipStreamSynchronize(stream));        // (read by launches on other streams; the power array may be freed by the caller now)
+    h->kp.se_pool = nullptr; h->kp.se_stride = 0;    // no RB-major pool: pooled tiles exist as sidecars only
+    h->se_tiles_n = n_tiles; h->se_mode = RANENV_SE_GATHER;
+    h->have_episodes = false;                        // descriptors are re-validated against the new tile count
     return RANENV_OK;
 }
 
@@ -3312,7 +3409,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     if (rc != RANENV_OK) return rc;
     if (n_steps < 1) return fail(h, RANENV_E_INVALID, "n_steps must be >= 1");
     if (h->kp.policy == RANENV_POLICY_EXTERNAL) return fail(h, RANENV_E_STATE, "a rollout needs a device policy (ranenv_set_policy MARR / MAPF)");
-    if (!h->kp.se_pool || (!h->kp.trf_pool && !h->kp.trf_gen)) return fail(h, RANENV_E_STATE, "a rollout replays the bound SE pool and traffic pool / generator");
+    const bool have_se = h->kp.se_pool != nullptr || (h->se_mode == RANENV_SE_GATHER && h->d_se_mean != nullptr);
+    if (!have_se || (!h->kp.trf_pool && !h->kp.trf_gen)) return fail(h, RANENV_E_STATE, "a rollout replays the bound SE pool and traffic pool / generator");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     KP kp = h->kp;
     kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
@@ -3342,7 +3440,12 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && (h->se_mode == RANENV_SE_GATHER ? (!h->small_batch || persist_tiny(h)) : persist_tiny(h))));
+    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && (h->se_mode == RANENV_SE_GATHER
+                                                                            ? ((!h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))
+                                                                            : persist_tiny(h))));
+    // (auto: where it was measured to win or tie -- profiles/r04_ab_log.txt.  Gather mode: B 1024 -4...-6 %, 2048 -1 %, 4096 -6 %, 8192 -2 % per
+    // TTI; a batch of several times what the chip holds -- 16 384 one-wave envs at the reference's own size -- swaps at every chunk and
+    // loses 7 %.  Streaming: parity from 2048 up, -10 % at <= 2 waves per SIMD with the whole-row build.)
     if (persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0) {
         for (int done_ttis = 0; done_ttis < n_steps;) {
             int n_tti = n_steps - done_ttis;
@@ -3514,7 +3617,7 @@ static int check_episode(ranenv_handle h, const ranenv_episode &e, const char *w
     if (e.se_len < 1 || e.se_offset < 0 || e.se_offset >= e.se_len || e.se_base < 0 || e.trf_len < 1 ||
         e.trf_offset < 0 || e.trf_offset >= e.trf_len || e.trf_base < 0)
         return fail(h, RANENV_E_INVALID, "%s %lld: need len >= 1, 0 <= offset < len, base >= 0", what, idx);
-    if (h->kp.se_pool && e.se_base + e.se_len > h->se_tiles_n)
+    if (h->se_tiles_n > 0 && e.se_base + e.se_len > h->se_tiles_n)
         return fail(h, RANENV_E_INVALID, "%s %lld: SE trace [%lld,+%d) exceeds the bound pool of %lld tiles", what, idx, (long long)e.se_base, e.se_len, (long long)h->se_tiles_n);
     if (h->kp.trf_pool && e.trf_base + e.trf_len > h->trf_rows_n)
         return fail(h, RANENV_E_INVALID, "%s %lld: traffic trace [%lld,+%d) exceeds the bound pool of %lld rows", what, idx, (long long)e.trf_base, e.trf_len, (long long)h->trf_rows_n);
@@ -3568,7 +3671,8 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     if (!h->ar_on) return fail(h, RANENV_E_STATE, "auto-reset is not configured (ranenv_set_autoreset)");
     int rc = check_ready(h, nullptr, nullptr, false);
     if (rc != RANENV_OK) return rc;
-    if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
+    if (!h->kp.se_pool && !(h->se_mode == RANENV_SE_GATHER && h->d_se_mean))
+        return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
     const AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
@@ -3591,7 +3695,8 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
     if (part < 0 || part >= h->n_parts || h->part_lo.empty()) return fail(h, RANENV_E_INVALID, "partition %d outside [0,%d) (ranenv_set_partitions)", part, h->n_parts);
     int rc = check_ready(h, nullptr, nullptr, false);
     if (rc != RANENV_OK) return rc;
-    if (!h->kp.se_pool) return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
+    if (!h->kp.se_pool && !(h->se_mode == RANENV_SE_GATHER && h->d_se_mean))
+        return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_, ps = h->part_stream[(size_t)part];
     if (stream != ps) {

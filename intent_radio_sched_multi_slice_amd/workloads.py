@@ -90,12 +90,14 @@ def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POL
                              n_scenarios: int = 200, n_traces: int = 200, trace_len: int = 200, seed: int = 10,
                              n_slices: int = 10, n_ues: int = 100, n_rbs: int = 135, rbs_per_rbg: int = 1,
                              max_ues_slice: int = 10, max_steps: int = 1000, rank: int = 0,
-                             name: Optional[str] = None, flags: int = 0) -> Workload:
+                             name: Optional[str] = None, flags: int = 0, min_slices: Optional[int] = None,
+                             min_ues: Optional[int] = None) -> Workload:
     """BASELINE configs 2-4: S 10 / U 100 / R 135 allocation units, 6..10 active slices with
     distinct templates, 4..10 UEs per slice, MimicQuadriga-law SE replayed from HBM."""
     tables = generate_scaled_scenarios(n_scenarios, seed=seed, n_slices=n_slices, n_ues=n_ues,
                                        max_ues_slice=max_ues_slice,
-                                       min_slices=min(6, n_slices), min_ues=min(4, max_ues_slice))
+                                       min_slices=min(6, n_slices) if min_slices is None else min_slices,
+                                       min_ues=min(4, max_ues_slice) if min_ues is None else min_ues)
     env = BatchedRanEnv(batch=batch, n_slices=n_slices, n_ues=n_ues, n_rbs=n_rbs, rbs_per_rbg=rbs_per_rbg,
                         max_ues_slice=max_ues_slice, n_scenarios=n_scenarios, max_steps=max_steps,
                         device=device, flags=flags)
@@ -167,6 +169,12 @@ def make_bench_workload(config: int, device: torch.device, batch: Optional[int] 
                                           n_traces=n_traces, trace_len=trace_len, rank=rank)
         label = ("mult_slice_seq per-scenario sweep, 10 scenario groups with 3..10 active slices (mixed masks and "
                  "intent metric sets), 100 UEs, 135 RBGs, MAPF + PF + ib_sched intent observation/reward")
+    elif config == 5:       # not a BASELINE config: the size every reference agent is actually trained at
+        wl = make_mult_slice_workload(batch or 16384, device, policy=POLICY_MAPF, intra=INTRA_PF, n_scenarios=200, n_traces=n_traces,
+                                      trace_len=trace_len, rank=rank, n_slices=5, n_ues=25, n_rbs=135, rbs_per_rbg=5, max_ues_slice=5,
+                                      min_slices=3, min_ues=2)          # 3..5 active slices of 2..5 UEs (associations/mult_slice.py:359-423)
+        label = ("reference-native size (env_config/mult_slice.yml:2-14, agents/ib_sched.py:50,56): 5 slices, 25 UEs, 27 RBGs of 5 "
+                 "RBs, MAPF inter-slice + PF intra-slice + ib_sched intent observation/reward")
     else:
         raise ValueError(f"no bench workload for BASELINE configs[{config}]")
     if traffic == "philox":

@@ -522,3 +522,52 @@ def test_options_are_set_and_read_back_and_unknown_keys_fail():
     env.reset(); env.rollout(9); torch.cuda.synchronize()      # still steps under the odd settings
     assert int(env.views()["step_number"].min()) == 9
     env.close()
+
+
+def test_gather_only_ingest_from_power_equals_pool_then_gather():
+    """ranenv_bind_se_gather_from_power (channels/quadriga.py:56-76 for a gather-only user): the sidecars straight from QuaDRiGa
+    received power are bit for bit those built from the RB-major pool ranenv_se_from_power writes, a handle without any RB-major
+    pool resets / steps / rolls out / auto-resets to the same state, and what needs whole rows says so."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd._lib import RanEnvError
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload, quadriga_pool_from_power
+    dev = torch.device("cuda", 0)
+    n_traces, L, B = 6, 10, 96
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    envs = []
+    for mode in ("pool", "power"):
+        wl = make_mult_slice_workload(B, dev, n_scenarios=16, n_traces=n_traces, trace_len=L, max_steps=1000)
+        env = wl.env
+        if mode == "pool":
+            power = torch.rand((n_traces * L, env.R, env.U), generator=g, device=dev, dtype=torch.float64) * 4e-11 + 1e-14
+            keep_power = power
+            env.bind_se_pool(quadriga_pool_from_power(power, env.R))
+            env.set_se_mode("gather")
+        else:
+            env.bind_se_gather_from_power(keep_power)
+        eps = wl.env.episodes
+        env.set_episodes(scenario=eps["scenario"], se_base=eps["se_base"], se_len=eps["se_len"], se_offset=eps["se_offset"],
+                         trf_base=eps["trf_base"], trf_len=eps["trf_len"], trf_offset=eps["trf_offset"])
+        envs.append(wl)
+    a, b = envs
+    sa, sb = a.env.se_sidecars(), b.env.se_sidecars()
+    assert torch.equal(sa["row_mean"], sb["row_mean"]) and torch.equal(sa["ue_major"], sb["ue_major"])
+    assert b.env.se_mode == "gather"
+    for wl in envs:
+        wl.env.reset(); wl.env.rollout(13); wl.env.step(); wl.env.rollout(4)
+    torch.cuda.synchronize()
+    va, vb = comparable_views(a), comparable_views(b)
+    for k in va:
+        assert torch.equal(va[k], vb[k]), k
+    assert torch.equal(a.env.obs_inter, b.env.obs_inter) and torch.equal(a.env.obs_intra, b.env.obs_intra)
+    assert torch.equal(a.env.reward, b.env.reward)
+    with pytest.raises(RanEnvError):
+        b.env.set_se_mode("stream")                      # no RB-major pool to stream
+    with pytest.raises(RanEnvError):
+        b.env.step_dense(torch.zeros((B, b.env.U, b.env.R), dtype=torch.uint8, device=dev))
+    # explicit tiles still stream (whole rows are given), and binding a pool brings the streaming mode back
+    tiles = quadriga_pool_from_power(keep_power[torch.arange(B, device=dev) % keep_power.shape[0]].contiguous(), b.env.R)
+    b.env.step(se_tiles=tiles)
+    b.env.bind_se_pool(quadriga_pool_from_power(keep_power, b.env.R))
+    assert b.env.se_mode in ("stream", "gather")
+    a.env.close(); b.env.close()
