@@ -16,7 +16,8 @@ What is timed, each as blocks of EXACTLY K steps between barrier + device sync o
 is repeated until ~20 ms of stepping are sampled, the median block is reported (`repeats`, min / max beside it):
 
   value / roofline   the headline, SURVEY 8(d)'s streaming step kernel: `ranenv_rollout` (the K TTIs of the device
-                     policy enqueued in one call) over 3 batch partitions on 3 HIP streams
+                     policy enqueued in one call): one persistent work-queue launch per workgroup class where the library's
+                     auto rule picks it (batch 4096: yes), else launches of up to 10 TTIs over 3 batch partitions on 3 streams
   single_stream      the same K TTIs as env.step() in a loop: one launch per TTI on one stream
   pipelined_step     a learner in the loop: external inter-slice scores produced from each half's last observation
                      on that half's own stream, two half-batches stepped alternately (set_ranges / range_stream /
@@ -128,7 +129,7 @@ def block_stats(times, env_steps_per_block: float, steps: int):
 
 
 def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, kms, parts, pmc, metrics,
-               workload_extra="", extras=None):
+               workload_extra="", extras=None, persistent=False):
     """The ONE JSON line.  `value` and `roofline.frac` share the wall clock of the timed region (the median block: the
     whole TTI of the whole batch); the step kernel's per-launch duration (the dispatch's own timestamps, from the same
     K steps repeated with timing on) is listed beside it -- with partitions `parts` launches of batch/parts envs overlap."""
@@ -142,12 +143,21 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
     env_ttis_per_launch = kms.get("n_env_ttis", batch / parts * kms.get("n_ttis", n_launches)) / max(1, n_launches)
     launch_bytes = alg_bytes_env_step * env_ttis_per_launch                   # algorithmic bytes of the average launch
     launch_gbs = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    traffic = (pmc or {}).get("stream_rollout" if parts > 1 else "stream")
+    traffic = (pmc or {}).get("stream_rollout" if (parts > 1 or persistent) else "stream")
     moved_per_tti = traffic.get("hbm_bytes_per_tti") if traffic else None      # HBM bytes one TTI of the whole batch moves (counters)
-    schedule = (f"ranenv_rollout: the K TTIs of the device policy enqueued in one call, batch stepped as {parts} partitions on "
-                f"{parts} HIP streams, no host between TTIs; a launch of the step kernel takes its partition through "
-                f"{ttis_per_launch:.3g} TTIs on average (up to K/4, at most 10)") if parts > 1 else \
-        "one launch of the step kernel per TTI on one stream"
+    kname = "ranenv_persist_kernel<stream>" if persistent else "ranenv_core_kernel<STEP>"
+    if persistent:
+        schedule = (f"ranenv_rollout as a persistent work-queue launch (option persist, auto): the K TTIs of the device policy in ONE "
+                    f"launch per workgroup class ({n_launches} launch(es) for the timed call: envs sorted by the waves a compact step "
+                    f"needs, one wave per 64 slice members), grids of what the chip holds, an env changes hands through its XCD's "
+                    f"ready queue only when another env is waiting for a slot; no host between TTIs")
+    elif parts > 1:
+        schedule = (f"ranenv_rollout: the K TTIs of the device policy enqueued in one call, batch stepped as {parts} partitions on "
+                    f"{parts} HIP streams, no host between TTIs; a launch of the step kernel takes its partition through "
+                    f"{ttis_per_launch:.3g} TTIs on average (up to K/4, at most 10)")
+    else:
+        schedule = "one launch of the step kernel per TTI on one stream"
+    conc = n_launches if persistent else parts
     line = {
         "metric": "env-steps/s (batched TTIs) at mult_slice 10-slice/100-UE; 1->8 GPU scaling"
                   + (" [device-policy rollout over batch partitions; step-by-step and learner-in-the-loop schedules beside it]"
@@ -174,15 +184,15 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
                                         f"compact steps, {traffic.get('ttis_per_launch_and_partition', 0):.3g} TTIs per launch on average -- summed and "
                                         f"divided by the TTIs stepped; `traffic` = that per-TTI figure scaled to the env-TTIs of the average launch; "
                                         f"{traffic.get('date', 'undated')}; not measured in this run)") if traffic else None,
-                     "kernel": "ranenv_core_kernel<STEP> (%d concurrent launch(es) of it, %.3g TTIs per launch)" % (parts, ttis_per_launch),
+                     "kernel": "%s (%d concurrent launch(es) of it, %.3g TTIs per launch)" % (kname, conc, ttis_per_launch),
                      "algorithmic_bytes_per_env_step": alg_bytes_env_step,
                      "algorithmic_bytes_per_tti": alg_bytes,
-                     "dominant_kernel": {"name": "ranenv_core_kernel<STEP>", "ms": launch_ms, "n_launches": n_launches,
+                     "dominant_kernel": {"name": kname, "ms": launch_ms, "n_launches": n_launches,
                                          "envs_per_launch": env_ttis_per_launch / max(1e-9, ttis_per_launch), "ttis_per_launch": ttis_per_launch,
                                          "env_ttis_per_launch": env_ttis_per_launch,
                                          "algorithmic_bytes": launch_bytes,
                                          "achieved": launch_gbs, "frac": launch_gbs / HBM_PEAK_GBS,
-                                         "concurrent_launches": parts,
+                                         "concurrent_launches": conc,
                                          "source": "hipExtLaunchKernel start/stop events of every launch, the K steps repeated "
                                                    "right after the timed region under the same schedule"}},
         "metrics": metrics,
@@ -199,12 +209,12 @@ def gather_block(env, batch, world, steps, times, kms, parts, pmc):
     t = st["ms_per_step"] * 1e-3
     hbm_frac = b_env * batch / t / (HBM_PEAK_GBS * 1e9)
     out = dict(st)
-    persist = env.get_option("persist")
+    persistent = kms["n_launches"] > 0 and kms.get("n_ttis", 0) == steps * kms["n_launches"] and steps > 10
     out.update({"bytes_per_env_step": b_env,
                 "bytes_model": "4*R (allocated RBs, each read once) + 8*U (sidecar row of per-UE mean SE) + 180*U + S*(85+8*Us) + 4",
                 "hbm_frac": hbm_frac,
                 "kernel": "ranenv_persist_kernel<gather> (one persistent work-queue launch per workgroup class and rollout call)"
-                          if (persist == 1 or (persist < 0 and batch > 2048)) else "ranenv_core_kernel_gather<STEP>",
+                          if persistent else "ranenv_core_kernel_gather<STEP>",
                 "env_ttis_per_launch": kms.get("n_env_ttis", 0) / max(1, kms["n_launches"]),
                 "dominant_kernel_ms": kms["step"], "n_launches": kms["n_launches"],
                 "ttis_per_launch": kms.get("n_ttis", kms["n_launches"]) / max(1, kms["n_launches"]), "concurrent_launches": parts})
@@ -410,9 +420,10 @@ def main():
             env.set_se_mode("stream")
 
     if rank == 0:
+        persistent = kms["n_launches"] > 0 and kms.get("n_ttis", 0) == K * kms["n_launches"] and K > 10    # every launch ran all K TTIs
         line = build_line(args, world, batch, label, (env.S, env.U, env.R),
                           env.algorithmic_bytes_per_env_step("gather" if args.only_gather else "stream"),
-                          times, kms, parts, pmc, summarize(gathered.cpu()),
+                          times, kms, parts, pmc, summarize(gathered.cpu()), persistent=persistent,
                           workload_extra=(", Poisson traffic pool" if args.traffic == "pool"
                                           else ", Poisson traffic drawn on the device (Philox4x32-10)"),
                           extras=extras)

@@ -389,8 +389,8 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
  *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
  *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one
- *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win (SE gather mode with a batch above 8 workgroups
- *                                                 per CU; either mode with a batch that stays within 2 waves per SIMD), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
+ *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win or tie (a batch above 8 workgroups per CU and up to
+ *                                                 about twice what the chip holds; a batch that stays within 2 waves per SIMD), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
  *                                                 TTIs up to the next episode end: the envs are sorted by the waves a compact step
  *                                                 of theirs needs (64 slice members per wave), each class gets a grid of what the
  *                                                 chip holds, and a workgroup that finishes a chunk of TTIs hands its env over

@@ -180,7 +180,6 @@ struct KP {
     // persistent rollout (ranenv_persist_kernel): this launch's workgroup class
     const int32_t *p_list;            // the class's envs
     int p_count, p_chunk;             // how many; TTIs of an env between two visits of the work queue
-    int p_stagger;                    // one-chunk launches: workgroups start spread over this many steps of ~1.7 us (0 = together)
     struct PersistCtl *p_ctl;         // the class's counters and per-XCD queue heads
     unsigned long long *p_slots;      // [8][p_cap] queue entries {index + 1, item}
     int p_cap;                        // entries per queue (a power of two >= the batch)
@@ -1744,20 +1743,6 @@ DEVFN void persist_loop()
         pl.xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);      // HW_REG_XCC_ID, bits 3:0
     }
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    {
-        // A launch whose workgroups all keep their env for good (one chunk: a batch far below what the chip holds) starts them
-        // spread over about one TTI instead of together: in lock step every workgroup streams its SE tile at the same moment --
-        // 55 MB in one burst, then HBM idles while everybody allocates -- and the stream phase of every chain is as long as that
-        // burst takes.  Out of step a chain's stream phase is one memory latency.  (The workgroups do not meet again: nothing
-        // synchronises them.)
-        kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kc));
-        const int stagger = kc->p_stagger;
-        if (stagger > 0) {
-            const int k = (int)((((unsigned)blockIdx.x * 0x9E3779B1u) >> 20) % (unsigned)stagger);
-            for (int i = 0; i < k; i++) __builtin_amdgcn_s_sleep(64);          // ~1.7 us each
-        }
-    }
     for (;;) {
         {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -2278,7 +2263,6 @@ struct ranenv {
                                    // batch that fills the CUs, and either mode with a batch of <= 2 waves per SIMD
     int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
     int n_cus = 256;               // compute units of the device (ranenv_create)
-    int persist_stagger = 0;       // one-chunk persistent launches: start spread, in steps of ~1.7 us (see persist_loop)
     int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
@@ -2671,7 +2655,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
 {
     const int B = h->cfg.batch, NC = h->p_nclass;
     const bool gather = h->se_mode == RANENV_SE_GATHER;
-    kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0; kp.p_stagger = 0;
+    kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0;
     kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->d_perr;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
@@ -2705,7 +2689,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         KP kc = kp;
         // (every env of the class has a workgroup of its own and all of them are resident: nobody can ever be waiting, so the
         // launch is one chunk -- no looks at the queues, no staggered first chunk)
-        if (tiny && g == n) { kc.p_chunk = n_tti > 1 ? n_tti : 1; kc.p_stagger = n_tti >= 8 ? h->persist_stagger : 0; }
+        if (tiny && g == n) kc.p_chunk = n_tti > 1 ? n_tti : 1;
         kc.p_list = h->d_plist + (size_t)c * B; kc.p_count = n; kc.p_ctl = h->d_pctl + c;
         kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -2758,7 +2742,6 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist") { h->persist = v < 0 ? -1 : (v != 0 ? 1 : 0); return RANENV_OK; }
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
-    if (k == "persist_stagger") { h->persist_stagger = v < 0 ? 0 : (v > 64 ? 64 : (int)v); return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -2770,7 +2753,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid", "persist_stagger"};
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -2893,7 +2876,6 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "persist") *value = h->persist;
     else if (k == "persist_chunk") *value = h->persist_chunk;
     else if (k == "persist_grid") *value = h->persist_grid;
-    else if (k == "persist_stagger") *value = h->persist_stagger;
     else if (k.rfind("persist_stat_", 0) == 0) {      // keep / push / pop / fresh / idle_polls, summed over classes and XCDs
         static const char *const names[] = {"keep", "push", "pop", "fresh", "idle_polls"};
         int which = -1;
@@ -3440,12 +3422,12 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && (h->se_mode == RANENV_SE_GATHER
-                                                                            ? ((!h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))
-                                                                            : persist_tiny(h))));
+    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && ((!h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))));
     // (auto: where it was measured to win or tie -- profiles/r04_ab_log.txt.  Gather mode: B 1024 -4...-6 %, 2048 -1 %, 4096 -6 %, 8192 -2 % per
     // TTI; a batch of several times what the chip holds -- 16 384 one-wave envs at the reference's own size -- swaps at every chunk and
-    // loses 7 %.  Streaming: parity from 2048 up, -10 % at <= 2 waves per SIMD with the whole-row build.)
+    // loses 7 %.  Streaming: -10 % at <= 2 waves per SIMD with the whole-row build; at B 4096 0...-4 % for rollouts of 200 TTIs and
+    // -1.4...-4 % for rollouts of 20; between 1024 and 2048 envs (8 workgroups per CU: the 128-register build of the launch-per-chunk
+    // rollout) it stays off.)
     if (persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0) {
         for (int done_ttis = 0; done_ttis < n_steps;) {
             int n_tti = n_steps - done_ttis;
