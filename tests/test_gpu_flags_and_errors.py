@@ -400,3 +400,37 @@ def test_degenerate_scenarios_vs_oracle():
             assert int(g["rb_count"][0].sum()) == 0 and int(g["rb_count"][1].sum()) == 0      # nobody to give RBs to
             assert int(g["rb_count"][2, 7]) == R and int(g["rb_count"][2].sum()) == R          # one UE owns the carrier
         env.close()
+
+
+def test_partitioned_step_survives_stream_capture():
+    """the partition join asked hipStreamQuery about the caller's stream, which is illegal while that stream is
+    capturing.  A learner that graph-captures `env.step()` (partitions on handle-owned streams joined by events: a fork and
+    a join inside the capture) must get a graph that replays to the same state as eager steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    outs = []
+    for mode in ("eager", "graph"):
+        wl = make_mult_slice_workload(256, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000)
+        env = wl.env
+        env.set_partitions(3)
+        env.reset(); env.step(); torch.cuda.synchronize()
+        if mode == "eager":
+            for _ in range(6):
+                env.step()
+        else:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s, capture_error_mode="relaxed"):
+                    env.step(); env.step()
+            for _ in range(3):
+                g.replay()
+        torch.cuda.synchronize()
+        outs.append((env.obs_inter.clone(), env.obs_intra.clone(), env.reward.clone(), env.views()["step_number"].clone(),
+                     env.views()["queue_pkts"].clone()))
+        env.close()
+    assert int(outs[1][3].min()) == 7
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
