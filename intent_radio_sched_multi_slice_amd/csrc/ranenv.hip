@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdarg>
@@ -3428,7 +3429,19 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // loses 7 %.  Streaming: -10 % at <= 2 waves per SIMD with the whole-row build; at B 4096 0...-4 % for rollouts of 200 TTIs and
     // -1.4...-4 % for rollouts of 20; between 1024 and 2048 envs (8 workgroups per CU: the 128-register build of the launch-per-chunk
     // rollout) it stays off.)
-    if (persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0) {
+    // (auto: not when episodes end at many different TTIs inside this call -- per-env episode lengths, envs reset at different times:
+    // every episode end ends the persistent launches, re-sorts the envs and reads the class counts back; the launch-per-chunk
+    // rollout follows the ends per partition without a host sync)
+    bool persist_ok = persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0;
+    if (persist_ok && h->persist < 0 && follow) {
+        std::vector<int> ends;
+        for (int b = 0; b < h->cfg.batch && ends.size() <= 2; b++) {
+            const int d = max_steps_of_env(h, b) - steps[(size_t)b];
+            if (d < n_steps && std::find(ends.begin(), ends.end(), d) == ends.end()) ends.push_back(d);
+        }
+        if (ends.size() > 2) persist_ok = false;
+    }
+    if (persist_ok) {
         for (int done_ttis = 0; done_ttis < n_steps;) {
             int n_tti = n_steps - done_ttis;
             if (follow) {

@@ -276,3 +276,27 @@ def test_create_rejects_row_lengths_the_pairwise_plan_cannot_follow():
     for R in (488, 512):                       # valid plans: fail later (no GPU here) or succeed, but not on the size check
         st, msg = create(R)
         assert "pairwise" not in msg, (R, msg)
+
+
+def test_options_table_in_the_header_matches_the_library_and_the_environment_is_read_in_one_place():
+    """VERDICT r3 hygiene: every knob of the launch schedule is an option documented in include/ranenv.h ("Options"); the keys
+    the library accepts are exactly the documented ones, and csrc/ranenv.hip reads the process environment in ONE function."""
+    import re
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(repo, "include", "ranenv.h")).read()
+    src = open(os.path.join(repo, "intent_radio_sched_multi_slice_amd", "csrc", "ranenv.hip")).read()
+    table = hdr[hdr.index("/* Options:"):hdr.index("int ranenv_set_option")]
+    documented = set(re.findall(r'^ \*\s+(?:\.\.\. )?"(\w+)"', table, flags=re.M))
+    setter = src[src.index("int set_option(ranenv_handle h"):src.index("void apply_env_options")]
+    accepted = set(re.findall(r'k == "(\w+)"', setter))
+    if 'k.rfind("fuse_first"' in setter:
+        accepted |= {"fuse_first0", "fuse_first9"}
+    read_only = {"persist_errors"}
+    assert accepted <= documented, accepted - documented
+    assert documented - accepted <= read_only, documented - accepted - read_only
+    # every documented env variable is RANENV_<KEY>, and getenv appears inside apply_env_options only
+    env_fn = src[src.index("void apply_env_options"):src.index("}  // namespace", src.index("void apply_env_options"))]
+    assert src.count("getenv(") == env_fn.count("getenv(") == 2
+    for key in accepted - {"fuse_first0", "fuse_first9"}:
+        assert f'"{key}"' in env_fn, key
+        assert "RANENV_" + key.upper() in table, key
