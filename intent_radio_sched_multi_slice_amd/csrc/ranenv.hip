@@ -282,6 +282,14 @@ DEVFN double wave_sum_f64(double x)   // sum over the 64 lanes of the wave (all 
     };
     return (lane(x, 0) + lane(x, 16)) + (lane(x, 32) + lane(x, 48));
 }
+DEVFN double half_sum_f64(double x)   // sum over the 32 lanes of this lane's half of the wave (packed waves): two DPP rows, then across them
+{
+    x = row16_sum_f64(x);
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __shfl_xor((int)b, 16), hi = __shfl_xor((int)(b >> 32), 16);
+    const double y = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    return (threadIdx.x & 16) ? y + x : x + y;       // (lower row first in both lanes: one order of the two addends)
+}
 // global_atomic_add_f64 without a return value: nothing waits for it (the library is built with the atomic optimizer
 // off: every add here already comes from one lane)
 DEVFN void acc_add(double *p, double v)
@@ -408,6 +416,32 @@ struct SeStream {
 };
 
 
+// The same queue for a packed wave (two envs per wave: the tile differs between the halves, so no wave-uniform descriptor): each
+// lane walks its own column of its own tile through an ordinary global pointer.
+template <int SE_NQ>
+struct SeStreamLane {
+    float q[SE_NQ][8];
+    const float *col;              // tile + u
+    int U, R;
+    static constexpr int NSLOT = SE_NQ;
+    DEVFN void load(float (&dst)[8], int r0)
+    {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int r = r0 + j < R ? r0 + j : R - 1; dst[j] = col[(size_t)r * U]; }
+    }
+    DEVFN void init(const float *tile, int U_, int u, int R_)
+    {
+        col = tile + u; U = U_; R = R_;
+#pragma unroll
+        for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
+    }
+    DEVFN void take(int d, float (&x)[8], int) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = q[d][j];
+    }
+    DEVFN void refill(int d, int r0) { load(q[d], r0); }
+};
+
 // Sums of one row: `full` over all R RBs, `part` over the RBs selected by in(r).
 // Accumulators start at 0.0 instead of being initialised with the leaf's first group: 0.0 + x == x
 // exactly, so the result is numpy's bit for bit while the loop body stays branch-free; the only
@@ -509,17 +543,29 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
 // Loads: two 16-byte buffer loads per group with the whole offset in the VGPR (range-checked: a lane that has no group
 // left gets an offset past the descriptor and reads 0 without touching memory), two groups in flight per lane.
 // ---------------------------------------------------------------------------------------------
+template <int PACK = 1>
 DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c)
 {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, tile_bytes, 0x00020000);
     constexpr int OOB = 0x7ffffff0;
     const RowPlan pl = make_row_plan(R);
     const int tail = R & 7;
     typedef float v4f __attribute__((ext_vector_type(4)));
+    // (a packed wave's halves read different tiles: per-lane pointers and a predicate instead of a wave-uniform descriptor)
+    __amdgpu_buffer_rsrc_t rsrc;
+    if constexpr (PACK == 1) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, tile_bytes, 0x00020000);
     auto ld8 = [&](float (&q)[8], int off) {
-        const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-        const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, 0));
-        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+        if constexpr (PACK == 1) {
+            const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+            const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, 0));
+            q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+        } else {
+            v4f a = {0.0f, 0.0f, 0.0f, 0.0f}, b = a;
+            if (off < tile_bytes) {
+                const v4f *src = (const v4f *)((const char *)tile + off);
+                a = src[0]; b = src[1];
+            }
+            q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+        }
     };
     auto in = [=](int r) { return ((unsigned)r - s) < c; };
     double lg = 0.0, rg = 0.0;
@@ -673,10 +719,11 @@ template <int NP> DEVFN double *srow(SharedCore<NP> &sh, int s, int k) { return 
 // instead of a 64-bit address per array and lane (a VGPR pair and two vector adds each; the step kernel touches ~30 arrays).
 // The row address is made opaque where it is used: otherwise the optimiser forms array + row + lane once, as a 64-bit vector
 // value, and carries it from the load at the top of the step to the store at its end.
-template <typename T> DEVFN T &row_at(T *array, size_t row_bytes, unsigned lane_bytes)
+// (PACK = 2: two envs per wave, lanes 0-31 / 32-63 -- the row differs between the halves, so it is an ordinary per-lane address)
+template <int PACK = 1, typename T> DEVFN T &row_at(T *array, size_t row_bytes, unsigned lane_bytes)
 {
     char *row = (char *)array + row_bytes;
-    asm volatile("" : "+s"(row));
+    if constexpr (PACK == 1) asm volatile("" : "+s"(row));
     return *(T *)(row + lane_bytes);
 }
 
@@ -684,7 +731,7 @@ template <typename T> DEVFN T &row_at(T *array, size_t row_bytes, unsigned lane_
 // in a slice (slc, position pos).  q / mp / pk: queue length, buffer size, packet size; wsent: packets sent
 // in the window, hlen its length; sem: mean SE of the previous tile.  Rows of sh.rows are zero beyond a
 // slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
-template <int NP, typename P>
+template <int NP, int PACK = 1, typename P>
 DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen, bool have, int slc, int pos,
                        int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out)
 {
@@ -742,10 +789,10 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             }
             wave_sync();
         } else if (ok1) {
-            score = p.scores ? row_at(p.scores, (size_t)e * S * 8, (unsigned)s1 * 8u) : (nues1 > 0 ? 1.0 : -1.0);   // marr.py:40-47
+            score = p.scores ? row_at<PACK>(p.scores, (size_t)e * S * 8, (unsigned)s1 * 8u) : (nues1 > 0 ? 1.0 : -1.0);   // marr.py:40-47
         }
 #if RANENV_DIAG != 9
-        if (ok1) row_at(scores_out, (size_t)e * S * 8, (unsigned)s1 * 8u) = score;
+        if (ok1) row_at<PACK>(scores_out, (size_t)e * S * 8, (unsigned)s1 * 8u) = score;
 #endif
         if (tid < GRP) xs[3][s1] = score;
         wave_sync();
@@ -764,7 +811,8 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             nzf = my_v != 0.0;
             // compaction of the non-zero values in slice order (common.py:484-485): they move to the front,
             // the zeros fill the slots behind them: every slot is written exactly once
-            const unsigned gm = (unsigned)(__ballot(nzf) & 0xffffull), below = (1u << s1) - 1u;
+            // (a packed wave: this env's 16 slice lanes start at lane 32 of the wave for the second env)
+            const unsigned gm = (unsigned)((__ballot(nzf) >> (PACK == 2 ? (threadIdx.x & 32u) : 0u)) & 0xffffull), below = (1u << s1) - 1u;
             m_nz = __popc(gm); slot = nzf ? __popc(gm & below) : m_nz + __popc(~gm & below);
             xs[2][slot] = my_v; xs[3][s1] = my_v;
         }
@@ -902,26 +950,35 @@ struct StepCarry {
     double sem_prev;
 };
 
-template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, typename P>
+template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, int PACK = 1, typename P>
 DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,   // warm: `cy` holds what the previous TTI of this launch left
-                     SeStream<GATHER ? 1 : NQ> *se_carry = nullptr, const bool se_ready = false, const bool se_next = false)
+                     std::conditional_t<PACK == 2, SeStreamLane<GATHER ? 1 : NQ>, SeStream<GATHER ? 1 : NQ>> *se_carry = nullptr,
+                     const bool se_ready = false, const bool se_next = false)
 {                                     // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
-    __shared__ SharedCore<NP> sh;
+    // PACK = 2 (envs of at most 32 UEs, one-wave workgroups): the wave steps TWO envs, lanes 0-31 the first, lanes 32-63 the second --
+    // `tid` is the lane within the env's half, everything per env (index, counters, episode, tile, LDS image, row addresses) is a
+    // per-lane value that happens to be equal across a half, and the 16-lane slice groups are DPP rows 0 / 2 of the wave.
+    static_assert(PACK == 1 || (PACK == 2 && MODE == MODE_STEP && !PERSIST), "packed waves: step launches only");
+    constexpr int LW = WAVE / PACK;                  // lanes per env
+    __shared__ SharedCore<NP> shs[PACK];
+    int e_ = PACK == 2 ? e_in + (int)(threadIdx.x >> 5) : __builtin_amdgcn_readfirstlane(e_in);   // e_in: p.e0 + blockIdx.x (x PACK), or a persistent workgroup's env
+    int tid_ = PACK == 2 ? (int)(threadIdx.x & 31u) : (int)threadIdx.x;
+    SharedCore<NP> &sh = shs[PACK == 2 ? (threadIdx.x >> 5) : 0];
     auto &xr = sh.xr;
-    int e_ = __builtin_amdgcn_readfirstlane(e_in), tid_ = threadIdx.x;      // e_in: p.e0 + blockIdx.x, or the env a persistent workgroup took from its queue
     // (opaque to the optimiser: inside step_loop nothing derived from them is carried from one TTI to the next in registers)
-    asm volatile("" : "+s"(e_));
+    if constexpr (PACK == 1) asm volatile("" : "+s"(e_));
     asm volatile("" : "+v"(tid_));
     const int e = e_, tid = tid_;
     // (inside a persistent launch no thread ever leaves the body early -- there is no env mask inside a rollout and every wave
     // is needed again for the next env --, and the exits are compiled out: a divergent way out of the persistent loops would
     // make the loop-carried wave-uniform values divergent in the compiler's eyes)
-    if (!PERSIST && p.env_mask != nullptr && p.env_mask[e] == 0) return true;  // uniform per workgroup
+    if (!PERSIST && PACK == 1 && p.env_mask != nullptr && p.env_mask[e] == 0) return true;  // uniform per workgroup
     const int S = p.S, U = p.U, R = p.R, D = p.D, Us = p.Us;
     const int W = 2 * Us + 9;
-    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni = [](int v) { if constexpr (PACK == 2) return v; else return __builtin_amdgcn_readfirstlane(v); };
     auto uni64 = [](long long v) {
+        if constexpr (PACK == 2) return v;
         const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
@@ -984,7 +1041,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // (addressing: see row_at -- a uniform row per array, the lane's byte offset in one register)
     const size_t tb_row = ((size_t)sc * U + (compact ? (size_t)0 : (size_t)6 * (size_t)p.NSU)) * 4;
     const unsigned lane4 = (unsigned)lane * 4u;
-#define TBL(f) row_at(TB_##f(p), tb_row, lane4)
+#define TBL(f) row_at<PACK>(TB_##f(p), tb_row, lane4)
     int u, slc, ue_pos, pkt_size, max_pkts, max_age;
     if (!warm) {
         u = compact ? TBL(lane_ue) : lane;      // (set 1 is the identity: no load, and the state loads need not wait for it)
@@ -999,11 +1056,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     const bool act = tid < U && !(compact && slc < 0);
     // (wave 0 stays: it runs the slice roles; inside a persistent launch every wave stays -- the launch's blocks have as many
     // waves as the env's class needs)
-    if (!PERSIST && !warm && compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;
+    if (!PERSIST && PACK == 1 && !warm && compact && __builtin_amdgcn_ballot_w64(act) == 0 && tid >= WAVE) return true;
     const size_t er4 = (size_t)e * U * 4, er8 = (size_t)e * U * 8;      // this env's row of a per-UE array of 4- / 8-byte elements
     const unsigned u4 = (unsigned)u * 4u, u8 = (unsigned)u * 8u;
-#define UE4(f) row_at(ST_##f(p), er4, u4)
-#define UE8(f) row_at(ST_##f(p), er8, u8)
+#define UE4(f) row_at<PACK>(ST_##f(p), er4, u4)
+#define UE8(f) row_at<PACK>(ST_##f(p), er8, u8)
     // window pushes of this env so far (wraps; only differences are used); index of the first push behind the last clearing
     const int ptot = uni(warm ? cy.ptot : ST_push_total(p)[e]);
     const int cmark = uni(warm ? cy.cmark : ST_clear_mark(p)[e]);
@@ -1017,8 +1074,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if (!clear_hist) win_sent = UE8(win_sent);
     }
     // (this push's slots of the two rings: the addresses are formed where they are used, not carried through the step)
-    auto ring_s = [&]() { return &row_at(ST_ring_sent(p), ((size_t)e * D + npush) * U * 4, u4); };
-    auto ring_d = [&]() { return &row_at(ST_ring_drop(p), ((size_t)e * D + npush) * U * 4, u4); };
+    auto ring_s = [&]() { return &row_at<PACK>(ST_ring_sent(p), ((size_t)e * D + npush) * U * 4, u4); };
+    auto ring_d = [&]() { return &row_at<PACK>(ST_ring_drop(p), ((size_t)e * D + npush) * U * 4, u4); };
     int old_s = 0, old_d = 0;
     double traffic = 0.0;
     const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
@@ -1030,8 +1087,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if (!clear_hist) { win_drop = UE8(win_dropped); lastp = UE4(last_push); }
         if (hlen == D) { old_s = *ring_s(); old_d = *ring_d(); }
         if (MODE != MODE_RESET && !gen_traffic)
-            traffic = p.traffic_bits ? row_at(p.traffic_bits, er8, u8)
-                                     : (double)row_at(p.trf_pool, ((size_t)ep.trf_base + (size_t)trf_pos) * U * 4, u4);
+            traffic = p.traffic_bits ? row_at<PACK>(p.traffic_bits, er8, u8)
+                                     : (double)row_at<PACK>(p.trf_pool, ((size_t)ep.trf_base + (size_t)trf_pos) * U * 4, u4);
     };
     // When the rest of the UE's state is requested: behind the stream by default (see RANENV_DEFER_STATE: registers), but at
     // entry in the build that has registers to spare (the whole-row queue of a batch at <= 2 waves per SIMD): there its round
@@ -1040,17 +1097,17 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     if constexpr (DEFER == 0) rest_of_state();
     if (MODE == MODE_STEP && !warm) sem_prev = UE8(se_mean);
     double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
-    if (GATHER) sem_tile = row_at(p.se_mean_pool, (size_t)tile_no * U * 8, u8);
+    if (GATHER) sem_tile = row_at<PACK>(p.se_mean_pool, (size_t)tile_no * U * 8, u8);
     // the scenario's slice tables, parked in LDS below by wave 0 (the other waves may have left): up to two words per lane
     int st_si0 = 0, st_si1 = 0, st_pi0 = 0, st_pi1 = 0; double st_pf = 0.0, st_sf = 0.0;
     if (tid < WAVE && !warm) {
         const unsigned t4 = (unsigned)tid * 4u, t8 = (unsigned)tid * 8u;
-        if (tid < S * 8) st_si0 = row_at(TB_slice_i32(p), (size_t)sc * S * 32, t4);
-        if (tid + WAVE < S * 8) st_si1 = row_at(TB_slice_i32(p), (size_t)sc * S * 32, t4 + WAVE * 4u);
-        if (tid < S * 6) st_pi0 = row_at(TB_param_i32(p), (size_t)sc * S * 24, t4);
-        if (tid + WAVE < S * 6) st_pi1 = row_at(TB_param_i32(p), (size_t)sc * S * 24, t4 + WAVE * 4u);
-        if (tid < S * 3) st_pf = row_at(TB_param_f64(p), (size_t)sc * S * 24, t8);
-        if (tid < S * 2) st_sf = row_at(TB_slice_f64(p), (size_t)sc * S * 16, t8);
+        if (tid < S * 8) st_si0 = row_at<PACK>(TB_slice_i32(p), (size_t)sc * S * 32, t4);
+        if (tid + LW < S * 8) st_si1 = row_at<PACK>(TB_slice_i32(p), (size_t)sc * S * 32, t4 + LW * 4u);
+        if (tid < S * 6) st_pi0 = row_at<PACK>(TB_param_i32(p), (size_t)sc * S * 24, t4);
+        if (tid + LW < S * 6) st_pi1 = row_at<PACK>(TB_param_i32(p), (size_t)sc * S * 24, t4 + LW * 4u);
+        if (tid < S * 3) st_pf = row_at<PACK>(TB_param_f64(p), (size_t)sc * S * 24, t8);
+        if (tid < S * 2) st_sf = row_at<PACK>(TB_slice_f64(p), (size_t)sc * S * 16, t8);
     }
     // device policy: this TTI's allocation may have been made at the end of the previous step
     bool pre = false;
@@ -1061,7 +1118,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     if (pre) {
         rb_start = UE4(next_rb_start); rb_count = UE4(next_rb_count);
 #if RANENV_DIAG != 9
-        if (tid < S) row_at(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
+        if (tid < S) row_at<PACK>(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at<PACK>(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
 #endif
     }
     const int episode_no = warm ? uni(cy.episode_no) : (gen_traffic ? uni(ST_episode_no(p)[e]) : 0);
@@ -1071,23 +1128,24 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // in flight through the tail, the next entry and the next allocation -- ~8 us of the chain -- and the stream phase finds them
     // landed.  The registers are there (2 waves per SIMD: 256 VGPRs), nothing else of the chain depends on the tile.
     constexpr bool SE_AHEAD = PERSIST && !GATHER && MODE == MODE_STEP && NQ >= 8;
-    SeStream<GATHER ? 1 : NQ> se_local;
-    SeStream<GATHER ? 1 : NQ> &se1 = SE_AHEAD ? *se_carry : se_local;
+    typedef std::conditional_t<PACK == 2, SeStreamLane<GATHER ? 1 : NQ>, SeStream<GATHER ? 1 : NQ>> SeQ;
+    SeQ se_local;
+    SeQ &se1 = SE_AHEAD ? *se_carry : se_local;
     if (!GATHER && !(SE_AHEAD && se_ready)) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
     asm volatile("" ::: "memory");
     // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables.
     // A warm TTI finds both as it needs them: the tables are the scenario's, and every role writes a slice's rows at its
     // members' positions only, so what lies beyond them is still the zeros of the launch's first TTI.
     if (tid < WAVE && !warm) {
-        for (int i = tid; i < S * 4 * NP; i += WAVE) {
+        for (int i = tid; i < S * 4 * NP; i += LW) {
             const int sl0 = i / (4 * NP), rem = i - sl0 * (4 * NP), k0 = rem / NP, j0 = rem - k0 * NP;
             sh.rows[sl0][k0 * NP + j0] = 0.0;
         }
-        for (int i = tid; i < S * NP; i += WAVE) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; sh.flg[sl0][j0] = 0; }
+        for (int i = tid; i < S * NP; i += LW) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; sh.flg[sl0][j0] = 0; }
         if (tid < S * 8) (&sh.si[0][0])[tid] = st_si0;
-        if (tid + WAVE < S * 8) (&sh.si[0][0])[tid + WAVE] = st_si1;
+        if (tid + LW < S * 8) (&sh.si[0][0])[tid + LW] = st_si1;
         if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi0;
-        if (tid + WAVE < S * 6) (&sh.pi[0][0])[tid + WAVE] = st_pi1;
+        if (tid + LW < S * 6) (&sh.pi[0][0])[tid + LW] = st_pi1;
         if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
         if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
     }
@@ -1096,7 +1154,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
     if (MODE == MODE_STEP && !pre)
-        alloc_front<NP>(p, sh, tid, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
+        alloc_front<NP, PACK>(p, sh, tid, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
                     rb_start, rb_count, ST_policy_scores(p));
     RANENV_STAMP(2);
 
@@ -1109,7 +1167,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 #if RANENV_GATHER_STATE_FIRST
         rest_of_state();          // requested ahead of the gather: both latencies run together
 #endif
-        if (MODE == MODE_STEP) my_part = gather_part(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
+        if (MODE == MODE_STEP) my_part = gather_part<PACK>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1 || RANENV_DIAG == 10
@@ -1186,7 +1244,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             int2 *ring_env = ST_age_ring(p) + (size_t)e * L * U;        // (uniform; entry k of this UE at [k * U + u])
             int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
             auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
-            auto load_head = [&]() { const int2 en = row_at(ring_env, 0, (unsigned)(head * U + u) * 8u); front = en.x; front_rem = en.y; };
+            auto load_head = [&]() { const int2 en = row_at<PACK>(ring_env, 0, (unsigned)(head * U + u) * 8u); front = en.x; front_rem = en.y; };
             if (nent > 0 && front == t - max_age - 1) {         // receive: the bin older than max_age expires
                 dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
                 front_rem = 0;
@@ -1199,7 +1257,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             dropped += pkt_in - adm;
             if (adm > 0) {
                 int tail = head + nent; tail = tail >= L ? tail - L : tail;
-                row_at(ring_env, 0, (unsigned)(tail * U + u) * 8u) = make_int2(t, adm);
+                row_at<PACK>(ring_env, 0, (unsigned)(tail * U + u) * 8u) = make_int2(t, adm);
                 if (nent == 0) { front = t; front_rem = adm; }
                 nent++;
                 total += adm;
@@ -1228,7 +1286,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             for (; q != ptot; q++) {
                 int slot = npush - (ptot - q); slot += slot < 0 ? D : 0;
                 const unsigned so = (unsigned)(slot * U + u) * 4u;
-                int32_t *qs = &row_at(ST_ring_sent(p), (size_t)e * D * U * 4, so), *qd = &row_at(ST_ring_drop(p), (size_t)e * D * U * 4, so);
+                int32_t *qs = &row_at<PACK>(ST_ring_sent(p), (size_t)e * D * U * 4, so), *qd = &row_at<PACK>(ST_ring_drop(p), (size_t)e * D * U * 4, so);
                 if (q - cmark >= D) { win_sent -= *qs; win_drop -= *qd; }
                 *qs = 0; *qd = 0;
             }
@@ -1238,8 +1296,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         // more than D pushes would otherwise give up values of the era before (a reset steps every UE: full width).
         if (MODE == MODE_RESET && clear_hist) {
             for (int k = 0; k < D; k++) {
-                row_at(ST_ring_sent(p), ((size_t)e * D + k) * U * 4, u4) = 0;
-                row_at(ST_ring_drop(p), ((size_t)e * D + k) * U * 4, u4) = 0;
+                row_at<PACK>(ST_ring_sent(p), ((size_t)e * D + k) * U * 4, u4) = 0;
+                row_at<PACK>(ST_ring_drop(p), ((size_t)e * D + k) * U * 4, u4) = 0;
             }
         }
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
@@ -1338,8 +1396,9 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     }
     if (MODE != MODE_RESET && (RANENV_METRICS && COLD(acc) != nullptr)) {
         // episode metrics: packet totals of the env, one add per wave (integers in doubles: exact in any order)
-        const double ws = wave_sum_f64((double)sent_u), wd = wave_sum_f64((double)drop_u);
-        if ((tid & (WAVE - 1)) == 0) { acc_add(COLD(acc) + (size_t)e * 8 + 6, ws); acc_add(COLD(acc) + (size_t)e * 8 + 7, wd); }
+        const double ws = PACK == 2 ? half_sum_f64((double)sent_u) : wave_sum_f64((double)sent_u);
+        const double wd = PACK == 2 ? half_sum_f64((double)drop_u) : wave_sum_f64((double)drop_u);
+        if ((tid & (LW - 1)) == 0) { acc_add(COLD(acc) + (size_t)e * 8 + 6, ws); acc_add(COLD(acc) + (size_t)e * 8 + 7, wd); }
     }
     RANENV_STAMP(5);
     if constexpr (SE_AHEAD) {
@@ -1372,8 +1431,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // The four means of every slice over its UEs -- the three drift rows and the SE row (common.py:343-378, ib_sched.py:146-157)
     // -- one per lane (lane = 16 * row + sorted position) instead of four one after the other on 16 lanes: they are
     // independent chains of LDS reads and additions, and this wave has nothing else to issue.
-    {
-        const int row4 = tid >> 4, sp4 = tid & (GRP - 1);
+    for (int pass4 = 0; pass4 < PACK; pass4++) {      // (a packed env has two 16-lane rows: the four means in two passes)
+        const int row4 = (tid >> 4) + 2 * pass4, sp4 = tid & (GRP - 1);
         double mean4 = 0.0;
         int s4 = 0, n4 = 0;
         if (sp4 < S) { s4 = sh.si[sp4][7]; n4 = sh.si[s4][2]; }
@@ -1450,7 +1509,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         for (int m = 0; m < 3; m++) {
             if (am[m] > 0.0) { r = (cnt == 0 || sv[m] < r) ? sv[m] : r; cnt++; }
         }
-        if (COLD(reward)) row_at(COLD(reward), (size_t)e * (S + 1) * 8, (unsigned)(s + 1) * 8u) = cnt > 0 ? r : 0.0;
+        if (COLD(reward)) row_at<PACK>(COLD(reward), (size_t)e * (S + 1) * 8, (unsigned)(s + 1) * 8u) = cnt > 0 ? r : 0.0;
         if (MODE == MODE_RESET) {
             ST_mask_inter(p)[(size_t)e * S + s] = (int8_t)active;
             for (int k = 0; k < Us; k++) ST_mask_intra(p)[((size_t)e * S + s) * Us + k] = k < n ? 1 : 0;
@@ -1485,7 +1544,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         dist = row16_sum_f64(fmin(my_ao, 0.0)); prio_dist = row16_sum_f64(fmin(my_ao * my_pr, 0.0));
     }
     const bool my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
-    const unsigned gm = (unsigned)(__ballot(my_sel) & 0xffffull);
+    const unsigned gm = (unsigned)((__ballot(my_sel) >> (PACK == 2 ? (threadIdx.x & 32u) : 0u)) & 0xffffull);
     const int m_sel = __popc(gm), cslot = __popc(gm & ((1u << tid) - 1u));
     xr[2][tid] = 0.0;
     wave_sync();
@@ -1534,11 +1593,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (COLD(obs_inter)) {
             float *dst = COLD(obs_inter) + (size_t)e * S * 10;
-            for (int i = tid; i < S * 10; i += WAVE) row_at(dst, 0, (unsigned)i * 4u) = sh.ob_inter[i];
+            for (int i = tid; i < S * 10; i += LW) row_at<PACK>(dst, 0, (unsigned)i * 4u) = sh.ob_inter[i];
         }
         if (COLD(obs_intra)) {
             float *dst = COLD(obs_intra) + (size_t)e * S * W;
-            for (int i = tid; i < S * W; i += WAVE) row_at(dst, 0, (unsigned)i * 4u) = sh.ob_intra[i];
+            for (int i = tid; i < S * W; i += LW) row_at<PACK>(dst, 0, (unsigned)i * 4u) = sh.ob_intra[i];
         }
     }
 #endif
@@ -1553,7 +1612,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     if (late) {
         wg_sync();                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
-        alloc_front<NP>(p, sh, tid, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
+        alloc_front<NP, PACK>(p, sh, tid, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
                     ns, nc, ST_next_scores(p));
         if (act) { UE4(next_rb_start) = ns; UE4(next_rb_count) = nc; }
     }
@@ -1575,7 +1634,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 // steps its env again as soon as it is done, from the state it has just written (its own CU's L1 / L2 hold it), instead
 // of ending and being launched again.  Between TTIs: every store of the workgroup is out and visible to its other
 // waves (__syncthreads = wait for the wave's memory operations + barrier; the waves of a workgroup share their CU's L1).
-template <int MODE, int NQ, bool GATHER, int NP, bool MANY>      // MANY: the build for launches of more than one TTI
+template <int MODE, int NQ, bool GATHER, int NP, bool MANY, int PACK = 1>      // MANY: the build for launches of more than one TTI
 DEVFN void step_loop(const KP &p)
 {
     if constexpr (MODE == MODE_STEP) {
@@ -1588,7 +1647,7 @@ DEVFN void step_loop(const KP &p)
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
-            if (step_body<MODE, NQ, GATHER, NP>(*kc, cy, warm, kc->e0 + (int)blockIdx.x)) return;
+            if (step_body<MODE, NQ, GATHER, NP, false, PACK>(*kc, cy, warm, kc->e0 + (int)blockIdx.x * PACK)) return;
             if (k + 1 < n) {
                 // The next TTI takes over in registers what it would otherwise load back (StepCarry) -- unless it has to look
                 // for an allocation made ahead (RANENV_LATE) -- and then only LDS has to be handed over between the waves.
@@ -1883,6 +1942,16 @@ template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU), RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU))))
 ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP, MANY>(p); }
 // Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
+
+// Packed waves (round 4): envs of at most 32 UEs and 8 slices -- the reference's own size, S 5 / U 25 -- leave 39 of a wave's 64 lanes
+// idle, and the chip holds as many waves as it holds; one wave steps TWO envs (lanes 0-31 / 32-63, step_body's PACK = 2): half as many
+// waves per env-step.  What is wave-uniform in the other builds is per-lane here (more registers: 4 waves per SIMD), so it is a build
+// of its own, for step launches of an even number of envs; reset and dense launches keep one env per wave (same state layout).
+template <int NP, bool MANY, bool GATHER>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_packed(const KP p)
+{
+    step_loop<MODE_STEP, GATHER ? 1 : 2, GATHER, NP, MANY, 2>(p);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Sidecars of the SE pool for the gather mode, built once per bound pool (ranenv_set_se_mode):
@@ -2264,6 +2333,7 @@ struct ranenv {
                                    // batch that fills the CUs, and either mode with a batch of <= 2 waves per SIMD
     int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
     int n_cus = 256;               // compute units of the device (ranenv_create)
+    bool pack = true;              // two envs per wave where the sizes allow (option "pack")
     int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
@@ -2438,6 +2508,23 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         h->prof_used += 2;
         h->prof_ttis += MODE == MODE_STEP ? kp.n_tti : 1;
         h->prof_env_ttis += (long long)n * (MODE == MODE_STEP ? kp.n_tti : 1);
+    }
+    if constexpr (MODE == MODE_STEP) {
+        // packed waves: two envs per wave for envs of <= 32 UEs / <= 8 slices (see ranenv_core_kernel_packed)
+        if (h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr) {
+            KP kq = kp;
+            kq.late = 0;
+            const dim3 pgrid((unsigned)(n / 2)), pblock((unsigned)WAVE);
+            const bool many = kq.n_tti > 1;
+#define PACKED_LAUNCH(MANY_, GATHER_) do { \
+                if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_packed<8, MANY_, GATHER_>), pgrid, pblock, 0, stream, ev0, ev1, 0, kq); \
+                else hipLaunchKernelGGL((ranenv_core_kernel_packed<8, MANY_, GATHER_>), pgrid, pblock, 0, stream, kq); } while (0)
+            if (gather) { if (many) PACKED_LAUNCH(true, true); else PACKED_LAUNCH(false, true); }
+            else { if (many) PACKED_LAUNCH(true, false); else PACKED_LAUNCH(false, false); }
+#undef PACKED_LAUNCH
+            if (kp.head_obs || kp.head_reward) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
+            return hipGetLastError();
+        }
     }
     switch (h->np) {
     case 8: launch_kernels<MODE, 8>(h, kp, grid, block, stream, ev0, ev1, gather); break;
@@ -2743,6 +2830,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist") { h->persist = v < 0 ? -1 : (v != 0 ? 1 : 0); return RANENV_OK; }
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
+    if (k == "pack") { h->pack = v != 0; return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -2754,7 +2842,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid"};
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid", "pack"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -2877,6 +2965,7 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "persist") *value = h->persist;
     else if (k == "persist_chunk") *value = h->persist_chunk;
     else if (k == "persist_grid") *value = h->persist_grid;
+    else if (k == "pack") *value = h->pack ? 1 : 0;
     else if (k.rfind("persist_stat_", 0) == 0) {      // keep / push / pop / fresh / idle_polls, summed over classes and XCDs
         static const char *const names[] = {"keep", "push", "pop", "fresh", "idle_polls"};
         int which = -1;
