@@ -389,6 +389,9 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
  *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
  *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one
+ *   "pack"         RANENV_PACK          1         envs of at most 32 UEs and 8 slices / 8 UEs per slice (the reference's own size) are stepped
+ *                                                 TWO per wave, lanes 0-31 / 32-63, wherever a step launch covers an even number of them
+ *                                                 (ranenv_set_partitions cuts an even batch into even ranges); 0: one env per wave
  *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win or tie (a batch above 8 workgroups per CU and up to
  *                                                 about twice what the chip holds; a batch that stays within 2 waves per SIMD), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
  *                                                 TTIs up to the next episode end: the envs are sorted by the waves a compact step

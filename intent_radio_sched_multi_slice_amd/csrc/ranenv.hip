@@ -3469,8 +3469,10 @@ int ranenv_set_partitions(ranenv_handle h, int32_t n_parts)
     }
     if (!h->ev_in) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
     h->part_lo.assign((size_t)n_parts + 1, 0);
-    const int B = h->cfg.batch, base = B / n_parts, rem = B % n_parts;
-    for (int k = 0; k < n_parts; k++) h->part_lo[k + 1] = h->part_lo[k] + base + (k < rem ? 1 : 0);
+    // (an even batch is cut into even ranges where that is possible: packed waves step two envs each, ranenv_core_kernel_packed)
+    const int B = h->cfg.batch, unit = (B % 2 == 0 && B / 2 >= n_parts) ? 2 : 1;
+    const int base = (B / unit) / n_parts, rem = (B / unit) % n_parts;
+    for (int k = 0; k < n_parts; k++) h->part_lo[k + 1] = h->part_lo[k] + unit * (base + (k < rem ? 1 : 0));
     h->n_parts = n_parts;
     return RANENV_OK;
 }

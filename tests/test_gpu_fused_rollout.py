@@ -230,3 +230,59 @@ def test_persistent_rollout_through_episode_ends(se_mode):
     assert int(a.env.episode_metrics()["episodes_done"].min()) >= 2
     assert b.env.get_option("persist_errors") == 0
     a.env.close(); b.env.close()
+
+
+# ---------------------------------------------------------------------------------------------- packed waves
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+@pytest.mark.parametrize("B", [2, 64, 4098])
+def test_two_envs_per_wave_equal_one_env_per_wave_at_the_reference_size(se_mode, B):
+    """Option pack (default on): envs of at most 32 UEs / 8 slices -- S 5, U 25, 27 RBGs of 5: the reference's own size -- are
+    stepped two per wave (lanes 0-31 / 32-63, ranenv_core_kernel_packed).  Same numbers bit for bit as one env per wave: rollouts
+    over 3 partitions (even ranges), single steps, external scores + per-slice intra choice, device auto-resets that change the
+    scenario, the device traffic generator."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    n_ep = 24
+    outs = []
+    for pack in (1, 0):
+        wl = make_mult_slice_workload(B, dev, policy=2, intra=1, n_scenarios=24, n_traces=12, trace_len=20, n_slices=5, n_ues=25,
+                                      n_rbs=135, rbs_per_rbg=5, max_ues_slice=5, max_steps=17, min_slices=3, min_ues=2)
+        env = wl.env
+        env.set_option("pack", pack); env.set_option("persist", 0)
+        env.set_se_mode(se_mode)
+        ep = np.arange(n_ep)
+        env.set_episode_table(scenario=(ep * 5) % 24, se_base=(ep % 12) * 20, se_len=20, se_offset=ep % 20,
+                              trf_base=((ep * 5) % 24) * 20, trf_len=20, trf_offset=(ep * 7) % 20)
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep)
+        env.enable_metrics(4)
+        if B > 2:
+            env.set_partitions(3)
+        env.reset()
+        snaps = []
+        env.rollout(9); snaps.append(_snap(env))
+        env.step(); snaps.append(_snap(env))
+        env.rollout(23); snaps.append(_snap(env))                      # across the episode end at TTI 17
+        g = torch.Generator(device=dev); g.manual_seed(11)
+        env.set_policy(0, 255)
+        for _ in range(3):
+            sc = torch.rand((B, env.S), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+            ic = torch.randint(0, 3, (B, env.S), generator=g, device=dev, dtype=torch.uint8)
+            env.step(sc, ic); snaps.append(_snap(env))
+        env.set_policy(1, 0)
+        env.set_traffic_generator(seed=77)
+        env.rollout(12); snaps.append(_snap(env))
+        m = env.episode_metrics()
+        snaps.append({"done_eps": m["episodes_done"].clone(), "log": m["episode_log"].clone(), "run": m["running"].clone()})
+        outs.append(snaps)
+        env.close()
+    for i, (x, y) in enumerate(zip(*outs)):
+        for k in x:
+            assert torch.equal(x[k], y[k]), (se_mode, B, i, k)
+
+
+def _snap(env):
+    torch.cuda.synchronize()
+    d = {k: v.clone() for k, v in env.views().items() if k != "se_mean"}
+    d.update(obs_inter=env.obs_inter.clone(), obs_intra=env.obs_intra.clone(), reward=env.reward.clone(), done=env.done.clone())
+    return d

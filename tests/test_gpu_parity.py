@@ -23,16 +23,20 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-@pytest.fixture(params=["lean", "small", "gather"])
+@pytest.fixture(params=["lean", "small", "gather", "packed", "packed-gather"])
 def build(request, monkeypatch):
     """The streaming step kernel has two builds (96 VGPRs / 8 SE loads in flight for batches that fill the CUs, 128 VGPRs /
     32 in flight for small ones); ranenv_create picks by batch size.  Test batches are small, so the choice is forced here
     (RANENV_SMALL_BATCH is read at create) and every case runs against both -- and against the SE gather mode
-    (RANENV_SE_MODE=gather: BatchedRanEnv.bind_se_pool switches it on, pooled tiles are then read through the sidecars)."""
-    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if request.param == "lean" else "1")
-    if request.param == "gather":
+    (RANENV_SE_MODE=gather: BatchedRanEnv.bind_se_pool switches it on, pooled tiles are then read through the sidecars).
+    "packed" / "packed-gather": option pack on (the default) -- envs of at most 32 UEs and 8 slices are stepped two per wave
+    (ranenv_core_kernel_packed) whenever a launch covers an even number of them; the other builds run with RANENV_PACK=0, so
+    that the one-env-per-wave kernels keep their coverage at the reference's own size."""
+    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if request.param in ("lean", "packed", "packed-gather") else "1")
+    monkeypatch.setenv("RANENV_PACK", "1" if request.param.startswith("packed") else "0")
+    if request.param.endswith("gather"):
         monkeypatch.setenv("RANENV_SE_MODE", "gather")
-    return request.param
+    return "gather" if request.param.endswith("gather") else request.param
 
 
 def _env(**kw):
@@ -62,7 +66,7 @@ def test_golden_traces(case, build):
     seed, steps_per_ep, cap = int(cfg[5]), int(cfg[7]), int(cfg[8])
     plumbing = len(cfg) > 9 and int(cfg[9]) == 1
     tabs = tables_from(fx)
-    B = 3
+    B = 4                          # (even: the packed build steps envs 0+1 and 2+3 in one wave each)
     env = _env(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
                n_scenarios=tabs.n_scenarios, bandwidth_hz=float(fx["bw"]), max_steps=steps_per_ep, max_age_cap=cap)
     env.load_scenarios(tabs)
@@ -89,7 +93,7 @@ def test_golden_traces(case, build):
             tr = np.broadcast_to(fx["traffic"][k], (B, U))
             obs, rew, done = env.step(sc, ic, tr, se)
             v = env.views()
-            for b in (0, B - 1):
+            for b in (0, 1, B - 1):
                 tag = (case, ep, t, b)
                 cnt = v["rb_count"][b].cpu().numpy()
                 st = v["rb_start"][b].cpu().numpy()

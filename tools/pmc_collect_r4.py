@@ -19,7 +19,7 @@ def summed(dirs, counter):
     for d in dirs:
         for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] == counter and re.search(r"ranenv_(core|persist)_kernel\w*<0[,>]|ranenv_persist_kernel", r["Kernel_Name"]):
+                if r["Counter_Name"] == counter and re.search(r"ranenv_(core|persist)_kernel\w*<0[,>]|ranenv_persist_kernel|ranenv_core_kernel_packed", r["Kernel_Name"]):
                     tot += float(r["Counter_Value"]); n += 1
     return (tot, n) if n else (None, 0)
 
