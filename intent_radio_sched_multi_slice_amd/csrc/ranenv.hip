@@ -2764,7 +2764,15 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
     if (demand == 0) return RANENV_OK;
     hipError_t e = ensure_streams(h, (size_t)(n_used > 1 ? n_used : 1));
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout, streams: %s", hipGetErrorString(e));
-    if (n_used > 1) HIP_TRY(h, hipEventRecord(h->ev_in, stream));
+    // (the other classes' streams pick up behind what the caller's stream holds -- unless it holds nothing: then there is nothing to
+    // wait for, and no signal has to cross between two hardware queues before the largest class may start; not while capturing)
+    bool join_in = n_used > 1;
+    if (join_in) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        if (cs == hipStreamCaptureStatusNone && hipStreamQuery(stream) == hipSuccess) join_in = false;
+    }
+    if (join_in) HIP_TRY(h, hipEventRecord(h->ev_in, stream));
     int k = 0;                                     // stream index: 0 = the caller's
     for (int c = NC - 1; c >= 0; c--) {
         const int n = h->pcount_host[(size_t)c];
@@ -2773,7 +2781,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         if (g < 1) g = 1;
         if (g > n) g = n;
         hipStream_t s = k == 0 ? stream : h->part_stream[(size_t)k];
-        if (k > 0) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_in, 0));
+        if (k > 0 && join_in) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_in, 0));
         KP kc = kp;
         // (every env of the class has a workgroup of its own and all of them are resident: nobody can ever be waiting, so the
         // launch is one chunk -- no looks at the queues, no staggered first chunk)
