@@ -35,5 +35,6 @@ step prof_gather 400 rocprofv3 --kernel-trace --stats -d $out/prof_gather -o p -
 step bench_cfg1 300 python3 bench.py --config 1 --no-cpu-baseline
 step bench_cfg4 300 python3 bench.py --config 4 --no-cpu-baseline
 step bench_native 400 python3 bench.py --config native --no-cpu-baseline
+RANENV_PACK=0 step bench_native_nopack 400 python3 bench.py --config native --no-cpu-baseline
 step bench_philox 300 python3 bench.py --traffic philox --no-cpu-baseline --no-gather
 echo "pass complete"
