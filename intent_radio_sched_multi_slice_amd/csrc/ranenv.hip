@@ -181,6 +181,7 @@ struct KP {
     // persistent rollout (ranenv_persist_kernel): this launch's workgroup class
     const int32_t *p_list;            // the class's envs
     int p_count, p_chunk;             // how many; TTIs of an env between two visits of the work queue
+    const int32_t *m_list; int m_count;   // mixed step launches (ranenv_core_kernel_mixed): the narrow class's envs (p_list / p_count: the wide class's)
     struct PersistCtl *p_ctl;         // the class's counters and per-XCD queue heads
     unsigned long long *p_slots;      // [8][p_cap] queue entries {index + 1, item}
     int p_cap;                        // entries per queue (a power of two >= the batch)
@@ -703,13 +704,22 @@ struct SharedCore {
 #ifndef RANENV_LDS_BARRIER
 #define RANENV_LDS_BARRIER 1
 #endif
-DEVFN void wg_sync()
+// `narrow`: this wave is a workgroup of its own inside a two-wave block (ranenv_core_kernel_mixed: two one-wave envs per block):
+// its exchanges through LDS are between its own lanes, so it waits for its LDS operations and must NOT take part in a block
+// barrier -- the block's other wave steps another env, or has left.
+DEVFN void wg_sync(const bool narrow = false)
 {
+    if (narrow) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
 #if RANENV_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
     __syncthreads();
 #endif
+}
+DEVFN void full_sync(const bool narrow = false)      // __syncthreads(), or for a narrow wave: its own memory operations only
+{
+    if (narrow) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); return; }
+    __syncthreads();
 }
 
 template <int NP> DEVFN double *srow(SharedCore<NP> &sh, int s, int k) { return &sh.rows[s][k * NP]; }
@@ -733,7 +743,8 @@ template <int PACK = 1, typename T> DEVFN T &row_at(T *array, size_t row_bytes, 
 // slice's UE count on entry and on exit (np_sum16_lds relies on it); the entries below it are scratch.
 template <int NP, int PACK = 1, typename P>
 DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen, bool have, int slc, int pos,
-                       int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out)
+                       int q, int mp, int pk, long long wsent, double sem, int &rb_start, int &rb_count, double *scores_out,
+                       const bool narrow = false)
 {
     auto &xs = sh.xr;
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
@@ -747,7 +758,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
     const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
     const bool has_pkts = have && !d_isclose(occ, 0.0);
     if (have) { r0[pos] = occ; r1[pos] = hm; sh.flg[sl][pos] = has_pkts ? 1 : 0; }
-    wg_sync();
+    wg_sync(narrow);
 
     // ---- inter-slice: lane t < 16 of wave 0 is slice t ----------------------------------------------
     if (tid < WAVE) {            // the other waves go straight to the barrier below
@@ -837,7 +848,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             sh.rbs[s1] = mine; sh.off[s1] = incl - mine;
         }
     }
-    wg_sync();
+    wg_sync(narrow);
 
     // ---- intra-slice: thread = UE; a slice's UEs exchange through its rows ---------------------------
     const int n = have ? sh.si[sl][2] : 0;
@@ -858,7 +869,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             avail = cap < backlog ? cap : backlog;
             r0[pos] = avail;                     // (the occupancy row was consumed by the inter-slice part)
         }
-        wg_sync();
+        wg_sync(narrow);
         double num = avail;                                                            // MT: weights = avail
         if (choice == RANENV_INTRA_PF) {                                               // :584-602
             double snt = hm * (double)pk;
@@ -873,12 +884,12 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             num = starved ? 2.0 * max_avail : avail / snt;
         }
         if (have) r1[pos] = num;
-        wg_sync();
+        wg_sync(narrow);
         const double wsum = np_sum_lds<NP>(r1, n);
         use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;                 // :603-608
         my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
         if (have) r2[pos] = my_val;
-        wg_sync();
+        wg_sync(narrow);
         unsigned gmv = 0;                        // which positions of the slice hold a non-zero value
 #pragma unroll
         for (int k = 0; k < NP; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
@@ -886,7 +897,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
         m_v = __popc(gmv);
         const int slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
         if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
-        wg_sync();
+        wg_sync(narrow);
         if (use_round) {
             const double tot = np_sum_lds<NP>(r3, m_v);
             prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
@@ -894,7 +905,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
     }
     if (!all_rr) {
         if (have) sh.cnt[sl][pos] = prop;
-        wg_sync();
+        wg_sync(narrow);
     }
     int count = 0;
     if (use_round) {
@@ -925,9 +936,9 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
     }
-    if (!all_rr) wg_sync();                                                  // every prop was read
+    if (!all_rr) wg_sync(narrow);                                                  // every prop was read
     if (have) sh.cnt[sl][pos] = count;
-    wg_sync();
+    wg_sync(narrow);
     int before = 0;                                                                // :464-478 contiguous ranges
 #pragma unroll
     for (int k = 0; k < NP; k++) before += k < pos ? sh.cnt[sl][k] : 0;
@@ -950,10 +961,10 @@ struct StepCarry {
     double sem_prev;
 };
 
-template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, int PACK = 1, typename P>
+template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, int PACK = 1, bool MIX = false, typename P>
 DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,   // warm: `cy` holds what the previous TTI of this launch left
                      std::conditional_t<PACK == 2, SeStreamLane<GATHER ? 1 : NQ>, SeStream<GATHER ? 1 : NQ>> *se_carry = nullptr,
-                     const bool se_ready = false, const bool se_next = false)
+                     const bool se_ready = false, const bool se_next = false, const bool narrow_in = false)
 {                                     // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     // PACK = 2 (envs of at most 32 UEs, one-wave workgroups): the wave steps TWO envs, lanes 0-31 the first, lanes 32-63 the second --
@@ -961,10 +972,15 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // per-lane value that happens to be equal across a half, and the 16-lane slice groups are DPP rows 0 / 2 of the wave.
     static_assert(PACK == 1 || (PACK == 2 && MODE == MODE_STEP && !PERSIST), "packed waves: step launches only");
     constexpr int LW = WAVE / PACK;                  // lanes per env
-    __shared__ SharedCore<NP> shs[PACK];
+    // MIX (ranenv_core_kernel_mixed): a two-wave block steps either one env of more than 64 slice members with both waves, or --
+    // `narrow` -- two envs of at most 64, one per wave, each wave a workgroup of its own: its own LDS image, lanes counted from its
+    // own first lane, no block barrier (wg_sync(narrow))
+    static_assert(!MIX || (PACK == 1 && MODE == MODE_STEP), "mixed blocks: step launches, one env per wave or per block");
+    const bool narrow = MIX && narrow_in;
+    __shared__ SharedCore<NP> shs[MIX ? 2 : PACK];
     int e_ = PACK == 2 ? e_in + (int)(threadIdx.x >> 5) : __builtin_amdgcn_readfirstlane(e_in);   // e_in: p.e0 + blockIdx.x (x PACK), or a persistent workgroup's env
-    int tid_ = PACK == 2 ? (int)(threadIdx.x & 31u) : (int)threadIdx.x;
-    SharedCore<NP> &sh = shs[PACK == 2 ? (threadIdx.x >> 5) : 0];
+    int tid_ = PACK == 2 ? (int)(threadIdx.x & 31u) : (narrow ? (int)(threadIdx.x & 63u) : (int)threadIdx.x);
+    SharedCore<NP> &sh = shs[PACK == 2 ? (threadIdx.x >> 5) : (narrow ? (threadIdx.x >> 6) : 0)];
     auto &xr = sh.xr;
     // (opaque to the optimiser: inside step_loop nothing derived from them is carried from one TTI to the next in registers)
     if constexpr (PACK == 1) asm volatile("" : "+s"(e_));
@@ -1149,13 +1165,13 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if (tid < S * 3) (&sh.pf[0][0])[tid] = st_pf;
         if (tid < S * 2) (&sh.sf[0][0])[tid] = st_sf;
     }
-    if (!warm) wg_sync();            // (a warm TTI starts behind step_loop's barrier)
+    if (!warm) wg_sync(narrow);            // (a warm TTI starts behind step_loop's barrier)
     RANENV_STAMP(1);
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
     if (MODE == MODE_STEP && !pre)
         alloc_front<NP, PACK>(p, sh, tid, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
-                    rb_start, rb_count, ST_policy_scores(p));
+                    rb_start, rb_count, ST_policy_scores(p), narrow);
     RANENV_STAMP(2);
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
@@ -1188,7 +1204,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
     }
     RANENV_STAMP(3);
-    wg_sync();        // every thread is done with the allocation's use of the per-slice rows
+    wg_sync(narrow);        // every thread is done with the allocation's use of the per-slice rows
     RANENV_STAMP(4);
 
     // ---- (2) UEs.step for UE tid -------------------------------------------------------------------
@@ -1409,7 +1425,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             asm volatile("" ::: "memory");
         }
     }
-    wg_sync();
+    wg_sync(narrow);
     RANENV_STAMP(6);
     do {
 #if RANENV_DIAG == 4 || RANENV_DIAG == 5 || RANENV_DIAG == 6 || RANENV_DIAG == 8   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
@@ -1610,10 +1626,10 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     if (MODE == MODE_STEP) late = false;
 #endif
     if (late) {
-        wg_sync();                     // (3) is done with the per-slice rows
+        wg_sync(narrow);                     // (3) is done with the per-slice rows
         int ns = 0, nc = 0;
         alloc_front<NP, PACK>(p, sh, tid, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
-                    ns, nc, ST_next_scores(p));
+                    ns, nc, ST_next_scores(p), narrow);
         if (act) { UE4(next_rb_start) = ns; UE4(next_rb_count) = nc; }
     }
     if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
@@ -1634,10 +1650,24 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 // steps its env again as soon as it is done, from the state it has just written (its own CU's L1 / L2 hold it), instead
 // of ending and being launched again.  Between TTIs: every store of the workgroup is out and visible to its other
 // waves (__syncthreads = wait for the wave's memory operations + barrier; the waves of a workgroup share their CU's L1).
-template <int MODE, int NQ, bool GATHER, int NP, bool MANY, int PACK = 1>      // MANY: the build for launches of more than one TTI
+template <int MODE, int NQ, bool GATHER, int NP, bool MANY, int PACK = 1, bool MIX = false>      // MANY: the build for launches of more than one TTI
 DEVFN void step_loop(const KP &p)
 {
     if constexpr (MODE == MODE_STEP) {
+        // MIX: which env(s) this block steps comes from the class lists (ranenv_persist_classify_kernel): the first p_count blocks take one
+        // env of the wide class each, the others two envs of the narrow class, one per wave
+        bool narrow = false;
+        int e_mix = 0;
+        if constexpr (MIX) {
+            const int b = (int)blockIdx.x;
+            if (b < p.p_count) e_mix = p.p_list[b];
+            else {
+                narrow = true;
+                const int idx = 2 * (b - p.p_count) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                if (idx >= p.m_count) return;             // (an odd number of narrow envs: the last block's second wave has none)
+                e_mix = p.m_list[idx];
+            }
+        }
         // Every TTI reads the kernel's arguments in place, through a pointer the optimiser cannot see through: nothing
         // derived from them is hoisted out of the loop and carried (= spilled) across a whole TTI.
         typedef const __attribute__((address_space(4))) KP *kp_const_t;
@@ -1647,12 +1677,12 @@ DEVFN void step_loop(const KP &p)
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
-            if (step_body<MODE, NQ, GATHER, NP, false, PACK>(*kc, cy, warm, kc->e0 + (int)blockIdx.x * PACK)) return;
+            if (step_body<MODE, NQ, GATHER, NP, false, PACK, MIX>(*kc, cy, warm, MIX ? e_mix : kc->e0 + (int)blockIdx.x * PACK, nullptr, false, false, narrow)) return;
             if (k + 1 < n) {
                 // The next TTI takes over in registers what it would otherwise load back (StepCarry) -- unless it has to look
                 // for an allocation made ahead (RANENV_LATE) -- and then only LDS has to be handed over between the waves.
                 warm = MANY && RANENV_WARM_ENTRY && kc->late == 0;
-                if (warm) wg_sync(); else __syncthreads();
+                if (warm) wg_sync(narrow); else full_sync(narrow);
             }
         }
     } else {
@@ -1942,6 +1972,17 @@ template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU), RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU))))
 ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP, MANY>(p); }
 // Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
+
+// Mixed blocks (round 4): a step launch of one two-wave workgroup per env holds ~2 560 envs of 100 UEs at a time (and its compact form
+// ~3 700: the idle second wave of an env of <= 64 slice members still needs a slot to start), so a TTI of 4096 envs is two rounds.
+// Here the launch is one block per env of the WIDE class (> 64 members: both waves) and one block per TWO envs of the NARROW class
+// (one wave each, no block barrier between them): 1 023 + 1 537 blocks = every wave slot of the chip, the whole batch resident in one
+// round.  Compact lane order (the classes are defined by it); the env lists are the persistent rollout's.
+template <int NP, bool MANY, bool GATHER>
+__global__ void __launch_bounds__(2 * WAVE) RANENV_CORE_ATTR ranenv_core_kernel_mixed(const KP p)
+{
+    step_loop<MODE_STEP, GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP, MANY, 1, true>(p);
+}
 
 // Packed waves (round 4): envs of at most 32 UEs and 8 slices -- the reference's own size, S 5 / U 25 -- leave 39 of a wave's 64 lanes
 // idle, and the chip holds as many waves as it holds; one wave steps TWO envs (lanes 0-31 / 32-63, step_body's PACK = 2): half as many
@@ -2334,6 +2375,7 @@ struct ranenv {
     int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
     int n_cus = 256;               // compute units of the device (ranenv_create)
     bool pack = true;              // two envs per wave where the sizes allow (option "pack")
+    bool mix = true;               // whole-batch step launches of two-wave workgroups as mixed blocks (option "mix")
     int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
@@ -2476,6 +2518,9 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
     launch_kernels_of<MODE, NP, false>(h, kp, grid, block, stream, ev0, ev1, gather);
 }
 
+int persist_prepare(ranenv_handle h, hipStream_t stream);
+bool persist_tiny(ranenv_handle h);
+
 // One launch of the step kernel for envs [e0, e0 + n) on `stream` (+ the head kernel when bound).
 template <int MODE>
 hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t stream)
@@ -2490,7 +2535,15 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     // loads are coalesced in that order (a wave reads 256 contiguous bytes per RB; slice members first scatters its lanes
     // over the whole 400-byte row), so they step compactly only where it was measured to win: under ranenv_rollout's
     // overlapping partitions (-4 %; +15 % for two alternating ranges, +1.5 % for one launch per TTI).
-    if (!gather && kp.compact != 2) kp.compact = 0;
+    // Mixed blocks (ranenv_core_kernel_mixed): the whole batch in one launch of one block per wide env + one per two narrow envs -- all of it
+    // resident in one round.  For launches of the whole batch of two-wave workgroups, where a compact step is exact.
+    bool mixed = false;
+    if constexpr (MODE == MODE_STEP) {
+        mixed = h->mix && kp.compact != 0 && h->nt == 2 * WAVE && e0 == 0 && n == h->cfg.batch && kp.env_mask == nullptr &&
+                !persist_tiny(h) && RANENV_DIAG == 0;
+        if (mixed && persist_prepare(h, stream) != RANENV_OK) return hipErrorUnknown;
+    }
+    if (!mixed && !gather && kp.compact != 2) kp.compact = 0;
     if (kp.compact) kp.compact = 1;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
@@ -2510,6 +2563,26 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         h->prof_env_ttis += (long long)n * (MODE == MODE_STEP ? kp.n_tti : 1);
     }
     if constexpr (MODE == MODE_STEP) {
+        if (mixed) {
+            const int B = h->cfg.batch, n_narrow = h->pcount_host[0], n_wide = h->pcount_host[1];
+            KP kq = kp;
+            kq.late = 0;
+            kq.p_list = h->d_plist + (size_t)B; kq.p_count = n_wide;
+            kq.m_list = h->d_plist; kq.m_count = n_narrow;
+            const dim3 mgrid((unsigned)(n_wide + (n_narrow + 1) / 2)), mblock((unsigned)(2 * WAVE));
+            const bool many = kq.n_tti > 1;
+#define MIXED_LAUNCH(NP_, MANY_, GATHER_) do { \
+                if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_mixed<NP_, MANY_, GATHER_>), mgrid, mblock, 0, stream, ev0, ev1, 0, kq); \
+                else hipLaunchKernelGGL((ranenv_core_kernel_mixed<NP_, MANY_, GATHER_>), mgrid, mblock, 0, stream, kq); } while (0)
+#define MIXED_NP(NP_) do { \
+                if (gather) { if (many) MIXED_LAUNCH(NP_, true, true); else MIXED_LAUNCH(NP_, false, true); } \
+                else { if (many) MIXED_LAUNCH(NP_, true, false); else MIXED_LAUNCH(NP_, false, false); } } while (0)
+            switch (h->np) { case 8: MIXED_NP(8); break; case 10: MIXED_NP(10); break; default: MIXED_NP(16); break; }
+#undef MIXED_NP
+#undef MIXED_LAUNCH
+            if (kp.head_obs || kp.head_reward) hipLaunchKernelGGL(ranenv_head_kernel, grid, dim3((unsigned)h->nslot), 0, stream, kp);
+            return hipGetLastError();
+        }
         // packed waves: two envs per wave for envs of <= 32 UEs / <= 8 slices (see ranenv_core_kernel_packed)
         if (h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr) {
             KP kq = kp;
@@ -2839,6 +2912,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
     if (k == "pack") { h->pack = v != 0; return RANENV_OK; }
+    if (k == "mix") { h->mix = v != 0; return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -2850,7 +2924,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid", "pack"};
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid", "pack", "mix"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -2974,6 +3048,7 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "persist_chunk") *value = h->persist_chunk;
     else if (k == "persist_grid") *value = h->persist_grid;
     else if (k == "pack") *value = h->pack ? 1 : 0;
+    else if (k == "mix") *value = h->mix ? 1 : 0;
     else if (k.rfind("persist_stat_", 0) == 0) {      // keep / push / pop / fresh / idle_polls, summed over classes and XCDs
         static const char *const names[] = {"keep", "push", "pop", "fresh", "idle_polls"};
         int which = -1;
