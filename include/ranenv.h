@@ -389,6 +389,10 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
  *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
  *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one
+ *   "mix"          RANENV_MIX           1         a step launch of the whole batch of two-wave workgroups (64 < U <= 128) runs as MIXED BLOCKS where a
+ *                                                 compact step is exact: one block per env of more than 64 slice members, one block per TWO envs
+ *                                                 of at most 64 (one wave each) -- the whole batch resident in one round; 0: never, 2: also for
+ *                                                 batches that fit the chip anyway (tests)
  *   "pack"         RANENV_PACK          1         envs of at most 32 UEs and 8 slices / 8 UEs per slice (the reference's own size) are stepped
  *                                                 TWO per wave, lanes 0-31 / 32-63, wherever a step launch covers an even number of them
  *                                                 (ranenv_set_partitions cuts an even batch into even ranges); 0: one env per wave

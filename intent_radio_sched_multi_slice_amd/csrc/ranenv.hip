@@ -2375,7 +2375,8 @@ struct ranenv {
     int persist_chunk = 10;        // TTIs of an env between two visits of the work queue
     int n_cus = 256;               // compute units of the device (ranenv_create)
     bool pack = true;              // two envs per wave where the sizes allow (option "pack")
-    bool mix = true;               // whole-batch step launches of two-wave workgroups as mixed blocks (option "mix")
+    int mix = 1;                   // whole-batch step launches of two-wave workgroups as mixed blocks (option "mix"): 0 never, 1 where the
+                                   // batch does not fit the chip anyway (auto), 2 also for batches that do (tests)
     int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
@@ -2539,8 +2540,8 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     // resident in one round.  For launches of the whole batch of two-wave workgroups, where a compact step is exact.
     bool mixed = false;
     if constexpr (MODE == MODE_STEP) {
-        mixed = h->mix && kp.compact != 0 && h->nt == 2 * WAVE && e0 == 0 && n == h->cfg.batch && kp.env_mask == nullptr &&
-                !persist_tiny(h) && RANENV_DIAG == 0;
+        mixed = h->mix != 0 && kp.compact != 0 && h->nt == 2 * WAVE && e0 == 0 && n == h->cfg.batch && kp.env_mask == nullptr &&
+                (h->mix == 2 || !persist_tiny(h)) && RANENV_DIAG == 0;
         if (mixed && persist_prepare(h, stream) != RANENV_OK) return hipErrorUnknown;
     }
     if (!mixed && !gather && kp.compact != 2) kp.compact = 0;
@@ -2801,7 +2802,7 @@ int persist_prepare(ranenv_handle h, hipStream_t stream)
     if (h->pclass_dirty) {
         HIP_TRY(h, hipMemsetAsync(h->d_pcount, 0, sizeof(int32_t) * (size_t)NC, stream));
         hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes,
-                           h->d_members, B, NC, persist_tiny(h) ? 1 : 0, h->d_plist, h->d_pcount);
+                           h->d_members, B, NC, (persist_tiny(h) && h->mix != 2) ? 1 : 0, h->d_plist, h->d_pcount);
         HIP_TRY(h, hipMemcpyAsync(h->pcount_host.data(), h->d_pcount, sizeof(int32_t) * (size_t)NC, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));
         h->pclass_dirty = false;
@@ -2912,7 +2913,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
     if (k == "pack") { h->pack = v != 0; return RANENV_OK; }
-    if (k == "mix") { h->mix = v != 0; return RANENV_OK; }
+    if (k == "mix") { h->mix = v < 0 ? 0 : (v > 2 ? 2 : (int)v); h->pclass_dirty = true; return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -3048,7 +3049,7 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "persist_chunk") *value = h->persist_chunk;
     else if (k == "persist_grid") *value = h->persist_grid;
     else if (k == "pack") *value = h->pack ? 1 : 0;
-    else if (k == "mix") *value = h->mix ? 1 : 0;
+    else if (k == "mix") *value = h->mix;
     else if (k.rfind("persist_stat_", 0) == 0) {      // keep / push / pop / fresh / idle_polls, summed over classes and XCDs
         static const char *const names[] = {"keep", "push", "pop", "fresh", "idle_polls"};
         int which = -1;

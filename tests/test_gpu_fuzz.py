@@ -37,12 +37,13 @@ def _draw_case(k):
 
 
 @pytest.mark.parametrize("k", range(N_CASES))
-@pytest.mark.parametrize("build", ["lean", "small", "gather", "packed"])
+@pytest.mark.parametrize("build", ["lean", "small", "gather", "packed", "mixed"])
 def test_fuzz_case_vs_oracle(k, build, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if build in ("lean", "packed") else "1")
+    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if build in ("lean", "packed", "mixed") else "1")
     monkeypatch.setenv("RANENV_PACK", "1" if build == "packed" else "0")      # (packed: two envs per wave where U <= 32 and S, Us <= 8)
+    monkeypatch.setenv("RANENV_MIX", "2" if build == "mixed" else "0")        # (mixed blocks where 64 < U <= 128 and the step is compact)
     if build == "gather":           # the SE gather mode: sidecars built at bind, tiles read through them
         monkeypatch.setenv("RANENV_SE_MODE", "gather")
     from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv

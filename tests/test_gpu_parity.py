@@ -23,7 +23,7 @@ def _need_gpu():
         pytest.skip("no GPU")
 
 
-@pytest.fixture(params=["lean", "small", "gather", "packed", "packed-gather"])
+@pytest.fixture(params=["lean", "small", "gather", "packed", "packed-gather", "mixed", "mixed-gather"])
 def build(request, monkeypatch):
     """The streaming step kernel has two builds (96 VGPRs / 8 SE loads in flight for batches that fill the CUs, 128 VGPRs /
     32 in flight for small ones); ranenv_create picks by batch size.  Test batches are small, so the choice is forced here
@@ -31,9 +31,13 @@ def build(request, monkeypatch):
     (RANENV_SE_MODE=gather: BatchedRanEnv.bind_se_pool switches it on, pooled tiles are then read through the sidecars).
     "packed" / "packed-gather": option pack on (the default) -- envs of at most 32 UEs and 8 slices are stepped two per wave
     (ranenv_core_kernel_packed) whenever a launch covers an even number of them; the other builds run with RANENV_PACK=0, so
-    that the one-env-per-wave kernels keep their coverage at the reference's own size."""
-    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if request.param in ("lean", "packed", "packed-gather") else "1")
+    that the one-env-per-wave kernels keep their coverage at the reference's own size.
+    "mixed" / "mixed-gather": whole-batch steps of two-wave workgroups (U > 64) as mixed blocks -- one block per env of more than 64
+    slice members, one per two envs of at most 64 (ranenv_core_kernel_mixed) -- forced for these small batches (RANENV_MIX=2); the
+    other builds run with RANENV_MIX=0."""
+    monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if request.param in ("lean", "packed", "packed-gather", "mixed", "mixed-gather") else "1")
     monkeypatch.setenv("RANENV_PACK", "1" if request.param.startswith("packed") else "0")
+    monkeypatch.setenv("RANENV_MIX", "2" if request.param.startswith("mixed") else "0")
     if request.param.endswith("gather"):
         monkeypatch.setenv("RANENV_SE_MODE", "gather")
     return "gather" if request.param.endswith("gather") else request.param

@@ -1,0 +1,18 @@
+#!/bin/bash
+set -o pipefail
+tag=${1:-r04mix}
+out=gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+step() {  # name timeout cmd...
+  local name=$1 to=$2; shift 2
+  timeout -k 10 $to "$@" > $out/$name.log 2>&1; local rc=$?
+  echo "[$name] rc=$rc"; grep -v amdgpu.ids $out/$name.log | grep -v "persist stats" | tail -n ${TAILN:-4} | cut -c1-400
+  if [ $rc -ne 0 ]; then echo "step $name failed: stopping"; exit 1; fi
+}
+step pytest_gpu 1000 python3 -m pytest tests -q -m gpu -x
+step probe_stream 300 python3 tools/step_probe.py
+RANENV_MIX=0 step probe_stream_nomix 300 python3 tools/step_probe.py
+RANENV_SE_MODE=gather step probe_gather 300 python3 tools/step_probe.py
+RANENV_SE_MODE=gather RANENV_MIX=0 step probe_gather_nomix 300 python3 tools/step_probe.py
+echo "pass complete"
