@@ -67,7 +67,7 @@ def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
     a.env.profile_begin(); a.env.step(); pa = a.env.profile_end()
     assert (pa["n_launches"], pa["n_ttis"]) == (3, 3)
     # the persistent rollout: one launch for all 40 TTIs of all 96 envs (a batch far below what the chip holds is one class)
-    a.env.set_option("persist", -1)
+    a.env.set_option("persist", -1); a.env.set_option("mix", 1)          # (mix = 2, a test setting, keeps two classes for small batches too)
     a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
     assert (pa["n_launches"], pa["n_ttis"], pa["n_env_ttis"]) == (1, 40, 96 * 40)
     a.env.close()
@@ -286,3 +286,47 @@ def _snap(env):
     d = {k: v.clone() for k, v in env.views().items() if k != "se_mean"}
     d.update(obs_inter=env.obs_inter.clone(), obs_intra=env.obs_intra.clone(), reward=env.reward.clone(), done=env.done.clone())
     return d
+
+
+# ---------------------------------------------------------------------------------------------- mixed blocks
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+@pytest.mark.parametrize("B", [37, 4096])
+def test_mixed_blocks_equal_one_workgroup_per_env(se_mode, B):
+    """Option mix: a whole-batch step launch as one block per env of more than 64 slice members and one block per TWO envs of at
+    most 64 (a wave each, no block barrier between them) -- ranenv_core_kernel_mixed -- against one two-wave workgroup per env:
+    single steps and multi-TTI launches (a rollout on one stream), device policy and external scores, bit for bit.  B = 37: forced
+    (mix = 2), an odd number of narrow envs (the last block's second wave has none)."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    outs = []
+    for mix in (2, 0):
+        wl = make_mult_slice_workload(B, dev, n_scenarios=32, n_traces=16, trace_len=24, max_steps=1000)
+        env = wl.env
+        env.set_option("mix", mix); env.set_option("persist", 0)
+        env.set_se_mode(se_mode)
+        env.reset()
+        snaps = []
+        for _ in range(4):
+            env.step()
+        snaps.append(_snap(env))
+        env.rollout(13); snaps.append(_snap(env))                      # one partition: launches of several TTIs over the whole batch
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        env.set_policy(0, 255)
+        for _ in range(3):
+            sc = torch.rand((B, env.S), generator=g, device=dev, dtype=torch.float64) * 2 - 1
+            ic = torch.randint(0, 3, (B, env.S), generator=g, device=dev, dtype=torch.uint8)
+            env.step(sc, ic)
+        snaps.append(_snap(env))
+        if mix:
+            env.profile_begin(); env.set_policy(2, 1); env.step(); k = env.profile_end()
+            members = (wl.tables.ue_slice[wl.scenario] >= 0).sum(axis=1)
+            assert k["n_launches"] == 1 and k["n_env_ttis"] == B and (members <= 64).sum() > 0 and (members > 64).sum() > 0
+        else:
+            env.set_policy(2, 1); env.step()
+        snaps.append(_snap(env))
+        outs.append(snaps)
+        env.close()
+    for i, (x, y) in enumerate(zip(*outs)):
+        for k in x:
+            assert torch.equal(x[k], y[k]), (se_mode, B, i, k)
