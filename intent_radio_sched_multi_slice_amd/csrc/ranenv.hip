@@ -181,7 +181,8 @@ struct KP {
     // persistent rollout (ranenv_persist_kernel): this launch's workgroup class
     const int32_t *p_list;            // the class's envs
     int p_count, p_chunk;             // how many; TTIs of an env between two visits of the work queue
-    const int32_t *m_list; int m_count;   // mixed step launches (ranenv_core_kernel_mixed): the narrow class's envs (p_list / p_count: the wide class's)
+    const int32_t *m_list;            // mixed step launches (ranenv_core_kernel_mixed): the narrow class's envs (p_list: the wide class's)
+    const int32_t *m_counts;          // ... and how many there are of each, on the device ([0] narrow, [1] wide): no host read-back
     struct PersistCtl *p_ctl;         // the class's counters and per-XCD queue heads
     unsigned long long *p_slots;      // [8][p_cap] queue entries {index + 1, item}
     int p_cap;                        // entries per queue (a power of two >= the batch)
@@ -1659,12 +1660,13 @@ DEVFN void step_loop(const KP &p)
         bool narrow = false;
         int e_mix = 0;
         if constexpr (MIX) {
-            const int b = (int)blockIdx.x;
-            if (b < p.p_count) e_mix = p.p_list[b];
+            // (the grid is the launch's env count, an upper bound: blocks beyond wide + ceil(narrow / 2) leave at once)
+            const int b = (int)blockIdx.x, n_wide = p.m_counts[1], n_narrow = p.m_counts[0];
+            if (b < n_wide) e_mix = p.p_list[b];
             else {
                 narrow = true;
-                const int idx = 2 * (b - p.p_count) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-                if (idx >= p.m_count) return;             // (an odd number of narrow envs: the last block's second wave has none)
+                const int idx = 2 * (b - n_wide) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                if (idx >= n_narrow) return;              // (also: an odd number of narrow envs, the last block's second wave has none)
                 e_mix = p.m_list[idx];
             }
         }
@@ -2398,8 +2400,8 @@ struct ranenv {
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
     int *d_perr = nullptr; int p_nclass = 0, p_cap = 0;
-    std::vector<int32_t> pcount_host; bool pclass_dirty = true;
-    int32_t *d_plist_part = nullptr, *d_pcount_part = nullptr; std::vector<int32_t> pcount_part_host; bool ppart_dirty = true;   // per partition
+    std::vector<int32_t> pcount_host; bool pclass_dirty = true, pcount_host_stale = true;
+    int32_t *d_plist_part = nullptr, *d_pcount_part = nullptr; bool ppart_dirty = true;   // per partition
     int p_wave_slots[2] = {0, 0};  // wave slots per CU of the persistent kernel (streaming, gather build), from the occupancy query
     long long prof_env_ttis = 0;   // env-TTIs covered by the launches timed since ranenv_profile_begin
     int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
@@ -2537,7 +2539,7 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
     launch_kernels_of<MODE, NP, false>(h, kp, grid, block, stream, ev0, ev1, gather);
 }
 
-int persist_prepare(ranenv_handle h, hipStream_t stream);
+int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts);
 int persist_prepare_parts(ranenv_handle h, hipStream_t stream);
 bool persist_tiny(ranenv_handle h);
 
@@ -2562,13 +2564,13 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     if constexpr (MODE == MODE_STEP) {
         mixed = h->mix != 0 && kp.compact != 0 && h->nt == 2 * WAVE && kp.env_mask == nullptr && (h->mix == 2 || !persist_tiny(h)) &&
                 RANENV_DIAG == 0;
-        if (mixed && e0 == 0 && n == h->cfg.batch) { if (persist_prepare(h, stream) != RANENV_OK) return hipErrorUnknown; }
+        if (mixed && e0 == 0 && n == h->cfg.batch) { if (persist_prepare(h, stream, false) != RANENV_OK) return hipErrorUnknown; }
         else if (mixed) {                               // a partition's range (ranenv_set_partitions): its own lists
             mixed = false;
             for (int k = 0; k < h->n_parts && h->n_parts > 1 && h->n_parts <= 16; k++)
                 if (h->part_lo[(size_t)k] == e0 && h->part_lo[(size_t)k + 1] - e0 == n) { mixed_part = k; mixed = true; }
             // (the lists are built on the CALLER's stream and read back: before any of the partitions' streams is used by this call)
-            if (mixed && h->ppart_dirty) mixed = false;
+            if (mixed && (h->ppart_dirty || h->ar_on)) mixed = false;
         }
     }
     if (!mixed && !gather && kp.compact != 2) kp.compact = 0;
@@ -2593,14 +2595,11 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     if constexpr (MODE == MODE_STEP) {
         if (mixed) {
             const int B = h->cfg.batch;
-            const int n_narrow = mixed_part < 0 ? h->pcount_host[0] : h->pcount_part_host[(size_t)mixed_part * 2 + 0];
-            const int n_wide = mixed_part < 0 ? h->pcount_host[1] : h->pcount_part_host[(size_t)mixed_part * 2 + 1];
             KP kq = kp;
             kq.late = 0;
-            if (mixed_part < 0) { kq.p_list = h->d_plist + (size_t)B; kq.m_list = h->d_plist; }
-            else { kq.p_list = h->d_plist_part + (size_t)B + e0; kq.m_list = h->d_plist_part + e0; }
-            kq.p_count = n_wide; kq.m_count = n_narrow;
-            const dim3 mgrid((unsigned)(n_wide + (n_narrow + 1) / 2)), mblock((unsigned)(2 * WAVE));
+            if (mixed_part < 0) { kq.p_list = h->d_plist + (size_t)B; kq.m_list = h->d_plist; kq.m_counts = h->d_pcount; }
+            else { kq.p_list = h->d_plist_part + (size_t)B + e0; kq.m_list = h->d_plist_part + e0; kq.m_counts = h->d_pcount_part + (size_t)mixed_part * 2; }
+            const dim3 mgrid((unsigned)n), mblock((unsigned)(2 * WAVE));       // (an upper bound of wide + ceil(narrow / 2))
             const bool many = kq.n_tti > 1;
 #define MIXED_LAUNCH(NP_, MANY_, GATHER_) do { \
                 if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_mixed<NP_, MANY_, GATHER_>), mgrid, mblock, 0, stream, ev0, ev1, 0, kq); \
@@ -2729,8 +2728,16 @@ int maybe_prepare_parts(ranenv_handle h, const KP &kp, hipStream_t stream)
 {
     if (h->mix == 0 || kp.compact == 0 || h->nt != 2 * WAVE || h->n_parts < 2 || h->n_parts > 16 || RANENV_DIAG != 0) return RANENV_OK;
     if (h->mix != 2 && persist_tiny(h)) return RANENV_OK;
-    if (!h->ppart_dirty) return RANENV_OK;
-    return persist_prepare_parts(h, stream);
+    // (with device auto-reset the lists go stale whenever a range restarts envs, while the other ranges' launches may be reading
+    // theirs: ranges then keep one workgroup per env)
+    if (h->ar_on || !h->ppart_dirty) return RANENV_OK;
+    // rare (a change of scenarios / episodes / partitions): nothing of this handle may be reading the old lists, and every stream
+    // that launches afterwards must see the new ones
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int rc = persist_prepare_parts(h, stream);
+    if (rc != RANENV_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    return RANENV_OK;
 }
 
 // What every launch of a call shares: the host's allocation generation, and whether the next TTI's allocation may be made
@@ -2826,7 +2833,7 @@ void launch_persist(int np, const KP &kp, dim3 grid, dim3 block, hipStream_t str
 }
 
 // The buffers of the work queues (once per handle) and, whenever scenarios / episodes changed, the envs sorted by class.
-int persist_prepare(ranenv_handle h, hipStream_t stream)
+int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
 {
     const int B = h->cfg.batch, NC = h->nt / WAVE;
     if (!h->d_plist) {
@@ -2844,9 +2851,12 @@ int persist_prepare(ranenv_handle h, hipStream_t stream)
         HIP_TRY(h, hipMemsetAsync(h->d_pcount, 0, sizeof(int32_t) * (size_t)NC, stream));
         hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes,
                            h->d_members, B, NC, (persist_tiny(h) && h->mix != 2) ? 1 : 0, h->d_plist, h->d_pcount);
+        h->pclass_dirty = false; h->pcount_host_stale = true;
+    }
+    if (need_host_counts && h->pcount_host_stale) {       // (the persistent launches size their grids by them; mixed launches read them on the device)
         HIP_TRY(h, hipMemcpyAsync(h->pcount_host.data(), h->d_pcount, sizeof(int32_t) * (size_t)NC, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));
-        h->pclass_dirty = false;
+        h->pcount_host_stale = false;
     }
     return RANENV_OK;
 }
@@ -2864,12 +2874,10 @@ int persist_prepare_parts(ranenv_handle h, hipStream_t stream)
         PartBounds pb;
         pb.n = np;
         for (int k = 0; k <= np && k < 17; k++) pb.lo[k] = h->part_lo[(size_t)k];
-        h->pcount_part_host.assign((size_t)NC * 16, 0);
         HIP_TRY(h, hipMemsetAsync(h->d_pcount_part, 0, sizeof(int32_t) * (size_t)NC * 16, stream));
         hipLaunchKernelGGL(ranenv_classify_parts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes, h->d_members,
                            B, NC, pb, h->d_plist_part, h->d_pcount_part);
-        HIP_TRY(h, hipMemcpyAsync(h->pcount_part_host.data(), h->d_pcount_part, sizeof(int32_t) * (size_t)NC * 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(h, hipStreamSynchronize(stream));
+        // (no read-back: the mixed launches read the counts on the device; the caller -- maybe_prepare_parts -- waits for the kernel)
         h->ppart_dirty = false;
     }
     return RANENV_OK;
@@ -3696,7 +3704,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
                 if (n_tti < 1) n_tti = 1;
             }
             if (n_tti >= (1 << (31 - PERSIST_ENV_BITS))) n_tti = (1 << (31 - PERSIST_ENV_BITS)) - 1;
-            rc = persist_prepare(h, stream);
+            rc = persist_prepare(h, stream, true);
             if (rc != RANENV_OK) return rc;
             rc = persist_launch(h, kp, n_tti, stream);
             if (rc != RANENV_OK) return rc;
