@@ -1934,23 +1934,6 @@ __global__ void __launch_bounds__(256) ranenv_persist_classify_kernel(const rane
     const int pos = atomicAdd(&count[c], 1);
     list[(size_t)c * B + pos] = e;
 }
-// The same per batch partition (mixed-block launches of a partition's range): the envs of partition k and class c at
-// list[c * B + lo[k] ...] (a partition has no more envs of a class than it has envs), counts at count[k * n_class + c].
-struct PartBounds { int n; int lo[17]; };
-__global__ void __launch_bounds__(256) ranenv_classify_parts_kernel(const ranenv_episode *eps, const int32_t *members, int B, int n_class,
-                                                                    PartBounds pb, int32_t *list, int32_t *count)
-{
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= B) return;
-    const int m = members[eps[e].scenario];
-    int c = m <= 0 ? 0 : (m + WAVE - 1) / WAVE - 1;
-    c = c < n_class ? c : n_class - 1;
-    int k = 0;
-    while (k + 1 < pb.n && e >= pb.lo[k + 1]) k++;
-    const int pos = atomicAdd(&count[k * n_class + c], 1);
-    list[(size_t)c * B + pb.lo[k] + pos] = e;
-}
-
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
 // 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 16 SE loads in flight per lane (8 until the build stopped hoisting
 // at machine level, which freed the registers for the second group) -- occupancy hides more latency than a still deeper
@@ -2401,7 +2384,6 @@ struct ranenv {
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
     int *d_perr = nullptr; int p_nclass = 0, p_cap = 0;
     std::vector<int32_t> pcount_host; bool pclass_dirty = true, pcount_host_stale = true;
-    int32_t *d_plist_part = nullptr, *d_pcount_part = nullptr; bool ppart_dirty = true;   // per partition
     int p_wave_slots[2] = {0, 0};  // wave slots per CU of the persistent kernel (streaming, gather build), from the occupancy query
     long long prof_env_ttis = 0;   // env-TTIs covered by the launches timed since ranenv_profile_begin
     int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
@@ -2540,7 +2522,6 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
 }
 
 int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts);
-int persist_prepare_parts(ranenv_handle h, hipStream_t stream);
 bool persist_tiny(ranenv_handle h);
 
 // One launch of the step kernel for envs [e0, e0 + n) on `stream` (+ the head kernel when bound).
@@ -2560,18 +2541,12 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     // Mixed blocks (ranenv_core_kernel_mixed): the whole batch in one launch of one block per wide env + one per two narrow envs -- all of it
     // resident in one round.  For launches of the whole batch of two-wave workgroups, where a compact step is exact.
     bool mixed = false;
-    int mixed_part = -1;
     if constexpr (MODE == MODE_STEP) {
-        mixed = h->mix != 0 && kp.compact != 0 && h->nt == 2 * WAVE && kp.env_mask == nullptr && (h->mix == 2 || !persist_tiny(h)) &&
-                RANENV_DIAG == 0;
-        if (mixed && e0 == 0 && n == h->cfg.batch) { if (persist_prepare(h, stream, false) != RANENV_OK) return hipErrorUnknown; }
-        else if (mixed) {                               // a partition's range (ranenv_set_partitions): its own lists
-            mixed = false;
-            for (int k = 0; k < h->n_parts && h->n_parts > 1 && h->n_parts <= 16; k++)
-                if (h->part_lo[(size_t)k] == e0 && h->part_lo[(size_t)k + 1] - e0 == n) { mixed_part = k; mixed = true; }
-            // (the lists are built on the CALLER's stream and read back: before any of the partitions' streams is used by this call)
-            if (mixed && (h->ppart_dirty || h->ar_on)) mixed = false;
-        }
+        // (whole-batch launches only: for the ranges of a partitioned batch per-range lists were built and measured -- two alternating
+        // ranges 47.8 against 48.0 us per TTI in gather mode, and the streaming kernel loses the lane = UE order it wants there: dropped)
+        mixed = h->mix != 0 && kp.compact != 0 && h->nt == 2 * WAVE && e0 == 0 && n == h->cfg.batch && kp.env_mask == nullptr &&
+                (h->mix == 2 || !persist_tiny(h)) && RANENV_DIAG == 0;
+        if (mixed && persist_prepare(h, stream, false) != RANENV_OK) return hipErrorUnknown;
     }
     if (!mixed && !gather && kp.compact != 2) kp.compact = 0;
     if (kp.compact) kp.compact = 1;
@@ -2597,8 +2572,7 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
             const int B = h->cfg.batch;
             KP kq = kp;
             kq.late = 0;
-            if (mixed_part < 0) { kq.p_list = h->d_plist + (size_t)B; kq.m_list = h->d_plist; kq.m_counts = h->d_pcount; }
-            else { kq.p_list = h->d_plist_part + (size_t)B + e0; kq.m_list = h->d_plist_part + e0; kq.m_counts = h->d_pcount_part + (size_t)mixed_part * 2; }
+            kq.p_list = h->d_plist + (size_t)B; kq.m_list = h->d_plist; kq.m_counts = h->d_pcount;
             const dim3 mgrid((unsigned)n), mblock((unsigned)(2 * WAVE));       // (an upper bound of wide + ceil(narrow / 2))
             const bool many = kq.n_tti > 1;
 #define MIXED_LAUNCH(NP_, MANY_, GATHER_) do { \
@@ -2721,25 +2695,6 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
     return hipSuccess;
 }
 
-// Mixed-block launches of the partitions' ranges need the class lists per partition: built here, on the caller's stream, before a call
-// hands its launches to the partitions' streams (a classification kernel and one read-back, once per change of scenarios / episodes /
-// partitions).
-int maybe_prepare_parts(ranenv_handle h, const KP &kp, hipStream_t stream)
-{
-    if (h->mix == 0 || kp.compact == 0 || h->nt != 2 * WAVE || h->n_parts < 2 || h->n_parts > 16 || RANENV_DIAG != 0) return RANENV_OK;
-    if (h->mix != 2 && persist_tiny(h)) return RANENV_OK;
-    // (with device auto-reset the lists go stale whenever a range restarts envs, while the other ranges' launches may be reading
-    // theirs: ranges then keep one workgroup per env)
-    if (h->ar_on || !h->ppart_dirty) return RANENV_OK;
-    // rare (a change of scenarios / episodes / partitions): nothing of this handle may be reading the old lists, and every stream
-    // that launches afterwards must see the new ones
-    HIP_TRY(h, hipDeviceSynchronize());
-    const int rc = persist_prepare_parts(h, stream);
-    if (rc != RANENV_OK) return rc;
-    HIP_TRY(h, hipStreamSynchronize(stream));
-    return RANENV_OK;
-}
-
 // What every launch of a call shares: the host's allocation generation, and whether the next TTI's allocation may be made
 // ahead (role 0').  It may only when nothing a later call passes can change it: with the intra-slice scheduler taken from
 // the step's own intra_choice argument (RANENV_INTRA_PER_SLICE) an allocation made at the end of TTI t would use TTI t's
@@ -2845,7 +2800,7 @@ int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
             dev_alloc(h, &h->d_perr, 1) != RANENV_OK)
             return RANENV_E_NOMEM;
         h->pcount_host.assign((size_t)NC, 0);
-        h->pclass_dirty = true; h->ppart_dirty = true;
+        h->pclass_dirty = true;
     }
     if (h->pclass_dirty) {
         HIP_TRY(h, hipMemsetAsync(h->d_pcount, 0, sizeof(int32_t) * (size_t)NC, stream));
@@ -2857,28 +2812,6 @@ int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
         HIP_TRY(h, hipMemcpyAsync(h->pcount_host.data(), h->d_pcount, sizeof(int32_t) * (size_t)NC, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));
         h->pcount_host_stale = false;
-    }
-    return RANENV_OK;
-}
-
-// The class lists per batch partition, for mixed-block launches of a partition's range (rebuilt with the whole-batch lists).
-int persist_prepare_parts(ranenv_handle h, hipStream_t stream)
-{
-    const int B = h->cfg.batch, NC = h->nt / WAVE, np = h->n_parts;
-    if (!h->d_plist_part) {
-        if (dev_alloc(h, &h->d_plist_part, (size_t)NC * B) != RANENV_OK || dev_alloc(h, &h->d_pcount_part, (size_t)NC * 16) != RANENV_OK)
-            return RANENV_E_NOMEM;
-        h->ppart_dirty = true;
-    }
-    if (h->ppart_dirty) {
-        PartBounds pb;
-        pb.n = np;
-        for (int k = 0; k <= np && k < 17; k++) pb.lo[k] = h->part_lo[(size_t)k];
-        HIP_TRY(h, hipMemsetAsync(h->d_pcount_part, 0, sizeof(int32_t) * (size_t)NC * 16, stream));
-        hipLaunchKernelGGL(ranenv_classify_parts_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes, h->d_members,
-                           B, NC, pb, h->d_plist_part, h->d_pcount_part);
-        // (no read-back: the mixed launches read the counts on the device; the caller -- maybe_prepare_parts -- waits for the kernel)
-        h->ppart_dirty = false;
     }
     return RANENV_OK;
 }
@@ -2986,7 +2919,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
     if (k == "pack") { h->pack = v != 0; return RANENV_OK; }
-    if (k == "mix") { h->mix = v < 0 ? 0 : (v > 2 ? 2 : (int)v); h->pclass_dirty = true; h->ppart_dirty = true; return RANENV_OK; }
+    if (k == "mix") { h->mix = v < 0 ? 0 : (v > 2 ? 2 : (int)v); h->pclass_dirty = true; return RANENV_OK; }
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -3239,7 +3172,7 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
         for (int ue = 0; ue < U; ue++) m += t->ue_slice[i * U + ue] >= 0 ? 1 : 0;
         h->members_host[(size_t)first + i] = m;
     }
-    h->pclass_dirty = true; h->ppart_dirty = true;
+    h->pclass_dirty = true;
     const size_t f = (size_t)first;
     const Tables &d = h->kp.tab;
     const KP &k = h->kp;
@@ -3322,7 +3255,7 @@ int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *eps, void *stream
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(h->d_episodes, eps, sizeof(ranenv_episode) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
-    h->have_episodes = true; h->alloc_gen++; h->idle_check_dirty = true; h->pclass_dirty = true; h->ppart_dirty = true;
+    h->have_episodes = true; h->alloc_gen++; h->idle_check_dirty = true; h->pclass_dirty = true;
     return RANENV_OK;
 }
 
@@ -3376,8 +3309,6 @@ int ranenv_step(ranenv_handle h, const double *scores, const uint8_t *intra, con
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     rc = compact_for(h, kp, (hipStream_t)stream, &kp.compact);
     if (rc != RANENV_OK) return rc;
-    rc = maybe_prepare_parts(h, kp, (hipStream_t)stream);
-    if (rc != RANENV_OK) return rc;
     hipError_t e = launch<MODE_STEP>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "step launch: %s", hipGetErrorString(e));
     return RANENV_OK;
@@ -3415,8 +3346,6 @@ int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count, con
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     finalize_kp(h, kp);
     rc = compact_for(h, kp, (hipStream_t)stream, &kp.compact);
-    if (rc != RANENV_OK) return rc;
-    rc = maybe_prepare_parts(h, kp, (hipStream_t)stream);
     if (rc != RANENV_OK) return rc;
     hipError_t e = launch_range<MODE_STEP>(h, kp, env_first, env_count, (hipStream_t)stream);
     if (e == hipSuccess && (h->cfg.flags & RANENV_F_SYNC_CHECK)) e = hipStreamSynchronize((hipStream_t)stream);
@@ -3634,7 +3563,7 @@ int ranenv_set_partitions(ranenv_handle h, int32_t n_parts)
     const int B = h->cfg.batch, unit = (B % 2 == 0 && B / 2 >= n_parts) ? 2 : 1;
     const int base = (B / unit) / n_parts, rem = (B / unit) % n_parts;
     for (int k = 0; k < n_parts; k++) h->part_lo[k + 1] = h->part_lo[k] + unit * (base + (k < rem ? 1 : 0));
-    h->n_parts = n_parts; h->ppart_dirty = true;
+    h->n_parts = n_parts;
     return RANENV_OK;
 }
 
@@ -3716,7 +3645,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
                 if (steps[(size_t)b] >= max_steps_of_env(h, b)) { any = true; steps[(size_t)b] = 0; }
             }
             if (!any) continue;
-            h->pclass_dirty = true; h->ppart_dirty = true;               // the restarted envs' scenarios
+            h->pclass_dirty = true;               // the restarted envs' scenarios
             hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, adv);
             const hipError_t re = launch_range<MODE_RESET>(h, kpr, 0, h->cfg.batch, stream);
             if (re != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout, reset launch: %s", hipGetErrorString(re));
@@ -3727,8 +3656,6 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // behind every step, and -- with auto-reset -- no episode end before the launch's last TTI.  How many: a quarter of
     // the rollout, at most 10 (measured, profiles/r03_ab_log.txt: longer launches gain nothing more and lengthen the
     // drain at the rollout's end, where the workgroups that waited for a free slot run last and alone).
-    rc = maybe_prepare_parts(h, kp, stream);
-    if (rc != RANENV_OK) return rc;
     int fuse = h->fuse > 0 ? h->fuse : (n_steps / 4 < 1 ? 1 : (n_steps / 4 > 10 ? 10 : n_steps / 4));
     if (kp.head_obs || kp.head_reward) fuse = 1;
     auto max_steps_of = [&](int b) { return h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b]; };
@@ -3779,7 +3706,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
             }
             if (!any) return hipSuccess;
             AdvanceArgs a = adv; a.e0 = e0;
-            h->pclass_dirty = true; h->ppart_dirty = true;
+            h->pclass_dirty = true;
             hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
             return launch_range<MODE_RESET>(h, kpr, e0, n, s);
         });
@@ -3925,7 +3852,7 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
     const AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
-    h->pclass_dirty = true; h->ppart_dirty = true;                      // (scenarios of the restarted envs)
+    h->pclass_dirty = true;                      // (scenarios of the restarted envs)
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
@@ -3955,7 +3882,7 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
     const int e0 = h->part_lo[(size_t)part], n = h->part_lo[(size_t)part + 1] - e0;
     AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
     a.e0 = e0;
-    h->pclass_dirty = true; h->ppart_dirty = true;
+    h->pclass_dirty = true;
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, ps, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
