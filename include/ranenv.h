@@ -396,8 +396,9 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "pack"         RANENV_PACK          1         envs of at most 32 UEs and 8 slices / 8 UEs per slice (the reference's own size) are stepped
  *                                                 TWO per wave, lanes 0-31 / 32-63, wherever a step launch covers an even number of them
  *                                                 (ranenv_set_partitions cuts an even batch into even ranges); 0: one env per wave
- *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win or tie (a batch above 8 workgroups per CU and up to
- *                                                 about twice what the chip holds; a batch that stays within 2 waves per SIMD), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
+ *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win (SE gather mode with a batch above 8 workgroups per CU
+ *                                                 and up to about twice what the chip holds; either mode with a batch that stays within 2 waves
+ *                                                 per SIMD; for the streaming kernel at B 4096 it is a tie and stays off), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
  *                                                 TTIs up to the next episode end: the envs are sorted by the waves a compact step
  *                                                 of theirs needs (64 slice members per wave), each class gets a grid of what the
  *                                                 chip holds, and a workgroup that finishes a chunk of TTIs hands its env over

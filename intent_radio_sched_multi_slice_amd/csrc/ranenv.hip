@@ -3604,12 +3604,12 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && ((!h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))));
+    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && ((h->se_mode == RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))));
     // (auto: where it was measured to win or tie -- profiles/r04_ab_log.txt.  Gather mode: B 1024 -4...-6 %, 2048 -1 %, 4096 -6 %, 8192 -2 % per
     // TTI; a batch of several times what the chip holds -- 16 384 one-wave envs at the reference's own size -- swaps at every chunk and
-    // loses 7 %.  Streaming: -10 % at <= 2 waves per SIMD with the whole-row build; at B 4096 0...-4 % for rollouts of 200 TTIs and
-    // -1.4...-4 % for rollouts of 20; between 1024 and 2048 envs (8 workgroups per CU: the 128-register build of the launch-per-chunk
-    // rollout) it stays off.)
+    // loses 7 %.  Streaming: -10 % at <= 2 waves per SIMD with the whole-row build; at B 4096 a tie: six same-box pairs against the
+    // launches of <= 10 TTIs over three partitions, between -5 and +6 % for rollouts of 200 TTIs (mean +0.2 %) and between -1 and +4 % for
+    // rollouts of 20 (mean +0.6 %) -- the streaming kernel is bound by HBM either way -- so there it stays off unless asked for.)
     // (auto: not when episodes end at many different TTIs inside this call -- per-env episode lengths, envs reset at different times:
     // every episode end ends the persistent launches, re-sorts the envs and reads the class counts back; the launch-per-chunk
     // rollout follows the ends per partition without a host sync)
