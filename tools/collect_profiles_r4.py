@@ -3,8 +3,9 @@ import csv, json, os, shutil, sys
 src = sys.argv[1]
 names = {"bench.log": "bench.py (default: --steps 200 --warmup 20)",
          "bench_driver.log": "bench.py --gpus 1 --steps 20 --warmup 5 (the driver's invocation)",
-         "bench_nopersist.log": "RANENV_PERSIST=0 bench.py (the round-3 schedule: launches of <= 10 TTIs over 3 partitions)",
-         "bench_driver_nopersist.log": "RANENV_PERSIST=0 bench.py --gpus 1 --steps 20 --warmup 5",
+         "bench_persist.log": "RANENV_PERSIST=1 bench.py (the streaming headline as persistent launches too)",
+         "bench_driver_persist.log": "RANENV_PERSIST=1 bench.py --gpus 1 --steps 20 --warmup 5",
+         "bench_r3sched.log": "RANENV_PERSIST=0 RANENV_MIX=0 bench.py (every schedule as in round 3)",
          "bench_cfg1.log": "bench.py --config 1", "bench_cfg4.log": "bench.py --config 4", "bench_native.log": "bench.py --config native",
          "bench_native_nopack.log": "RANENV_PACK=0 bench.py --config native (one env per wave)",
          "bench_philox.log": "bench.py --traffic philox"}

@@ -15,8 +15,9 @@ step() {  # name timeout cmd...
 if [ -z "$2" ]; then step pytest_gpu 900 python3 -m pytest tests -q -m gpu; fi
 step bench 900 python3 bench.py
 step bench_driver 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
-RANENV_PERSIST=0 step bench_nopersist 600 python3 bench.py --no-cpu-baseline
-RANENV_PERSIST=0 step bench_driver_nopersist 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
+RANENV_PERSIST=1 step bench_persist 600 python3 bench.py --no-cpu-baseline
+RANENV_PERSIST=1 step bench_driver_persist 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
+RANENV_PERSIST=0 RANENV_MIX=0 step bench_r3sched 600 python3 bench.py --no-cpu-baseline
 K=100; CALLS=2; TT=$((10 + K * CALLS))
 for mode in stream gather; do
   for c in FETCH_SIZE WRITE_SIZE; do
