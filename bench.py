@@ -16,14 +16,16 @@ What is timed, each as blocks of EXACTLY K steps between barrier + device sync o
 is repeated until ~20 ms of stepping are sampled, the median block is reported (`repeats`, min / max beside it):
 
   value / roofline   the headline, SURVEY 8(d)'s streaming step kernel: `ranenv_rollout` (the K TTIs of the device
-                     policy enqueued in one call): one persistent work-queue launch per workgroup class where the library's
-                     auto rule picks it (batch 4096: yes), else launches of up to 10 TTIs over 3 batch partitions on 3 streams
-  single_stream      the same K TTIs as env.step() in a loop: one launch per TTI on one stream
+                     policy enqueued in one call): launches of up to 10 TTIs over 3 batch partitions on 3 HIP streams
+                     (RANENV_PERSIST=1: as persistent work-queue launches, a tie for this kernel; the line says which ran)
+  single_stream      the same K TTIs as env.step() in a loop: one launch per TTI on one stream (mixed blocks: one block per env
+                     of more than 64 slice members + one per two envs of at most 64, the whole batch resident in one round)
   pipelined_step     a learner in the loop: external inter-slice scores produced from each half's last observation
                      on that half's own stream, two half-batches stepped alternately (set_ranges / range_stream /
                      step_async / step_wait)
-  se_gather          the headline schedule in the SE gather mode (ranenv_set_se_mode: per-tile mean-SE sidecar + reads
-                     of the allocated RBs only), with its own byte model and bound
+  se_gather          ranenv_rollout in the SE gather mode (ranenv_set_se_mode: per-tile mean-SE sidecar + reads of the
+                     allocated RBs only) -- as persistent work-queue launches, one per workgroup class --, with its own byte
+                     model and bound
 """
 from __future__ import annotations
 
