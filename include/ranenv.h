@@ -408,6 +408,9 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "persist_grid" RANENV_PERSIST_GRID  0         cap on the wave slots the persistent grids are sized for (0 = the occupancy
  *                                                 query x CUs); small values force hand-overs (tests)
  *   "persist_errors" (read only)                  waits of a persistent launch that gave up after ~1 s: 0 in every correct run
+ *   "persist_stat_keep" / "_push" / "_pop" / "_fresh" / "_idle_polls" (read only)   queue statistics of the persistent launches so far, summed over
+ *                                                 classes and XCDs: chunk ends at which the workgroup kept its env, envs put down, envs taken
+ *                                                 from a ready queue, envs taken fresh, spins on a slot whose pusher had not written yet
  *
  * Python host layer only (batched_env.py, not this library): RANENV_SE_MODE=gather makes BatchedRanEnv.bind_se_pool switch
  * to the SE gather mode, RANENV_LIB=<path> loads another build of this library.
