@@ -15,8 +15,11 @@ inter-slice reward as training goes on.  Measured on one MI355X (B = 4096, gathe
 (it depends on the box's host cores), about half of that with two -- the loop is bound by the HOST: an eager torch policy is
 ~15 small kernels per decision (250-600 us of Python and launch time per range and TTI against ~45 us of env step), and every
 further range adds that much host work per TTI.
-Ranges pay off once the policy costs the host little (a fused or graph-captured forward): `bench.py`'s `pipelined_step`
-runs the same schedule with a one-kernel policy at 55 M env-steps/s (~80 M in gather mode, tools/pipeprobe.py).
+Ranges pay off once the policy costs the host little (a fused or graph-captured forward) AND the env steps in the streaming
+mode: `bench.py`'s `pipelined_step` runs the same schedule with a one-kernel policy at 56 M env-steps/s against 49 M for plain
+`env.step()`.  In the gather mode the plain `env.step()` on one stream is the faster schedule since round 4 (a whole-batch step is
+one launch of mixed blocks, the whole batch resident in one round: 45.5 us per TTI against 47.8 for two ranges,
+tools/pipeprobe.py) -- one range, as this example defaults to.
 """
 import argparse
 import os
