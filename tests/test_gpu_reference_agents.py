@@ -198,12 +198,15 @@ def _exogenous_inputs_of_the_fixture(fx, name):
     return bua, bsa, sua, req, ues, np.stack(se).astype(np.float32), np.stack(traffic)
 
 
+@pytest.mark.parametrize("B", [3, 4], ids=["one-env-per-wave", "packed"])
 @pytest.mark.parametrize("name", ["ib_sched", "marr", "mapf"])
-def test_fused_step_kernel_against_the_real_agents_episode(name):
+def test_fused_step_kernel_against_the_real_agents_episode(name, B):
     """The same fixture through the BATCHED path: the fused step kernel does action_format, UEs.step, obs_space_format and
     calculate_reward itself.  For the real IBSched's episode it gets the fixture's scores and per-slice scheduler choices; for
     the real MARR's / MAPF's it gets nothing -- the device policy must produce the very scores the reference's agent.step
-    returned, TTI after TTI, in closed loop.  RB ranges, packets and occupancies exact, observations 1e-5, rewards 1e-9."""
+    returned, TTI after TTI, in closed loop.  RB ranges, packets and occupancies exact, observations 1e-5, rewards 1e-9.
+    B = 4: at this size -- the reference's own -- an even batch is stepped two envs per wave (ranenv_core_kernel_packed); the envs
+    compared are the second half of wave 0 (1), the first half of wave 0 (0) and the first half of wave 1 (2)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
@@ -214,7 +217,6 @@ def test_fused_step_kernel_against_the_real_agents_episode(name):
     marl = name == "ib_sched"
     tabs = ScenarioTables.empty(1, S, U, Us)
     tabs.set_from_reference(0, bsa, sua, req, marl, (ues.pkt_sizes, ues.max_buffer_pkts, ues.max_buffer_latencies))
-    B = 3
     env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us, n_scenarios=1, max_steps=steps)
     env.load_scenarios(tabs)
     env.set_episodes(scenario=0)
