@@ -69,7 +69,8 @@ def test_a_fused_launch_covers_the_ttis_it_says(monkeypatch):
     # the persistent rollout: one launch for all 40 TTIs of all 96 envs (a batch far below what the chip holds is one class)
     a.env.set_option("persist", -1); a.env.set_option("mix", 1)          # (mix = 2, a test setting, keeps two classes for small batches too)
     a.env.profile_begin(); a.env.rollout(40); pa = a.env.profile_end()
-    assert (pa["n_launches"], pa["n_ttis"], pa["n_env_ttis"]) == (1, 40, 96 * 40)
+    if a.env.get_option("compact"):                           # (it needs compact steps: not under the RANENV_COMPACT=0 pass of the suite)
+        assert (pa["n_launches"], pa["n_ttis"], pa["n_env_ttis"]) == (1, 40, 96 * 40)
     a.env.close()
     monkeypatch.setenv("RANENV_FUSE", "1")
     b = _bench_like(96, False)
