@@ -350,7 +350,9 @@ def main():
                 t1 = timed_blocks(lambda: [env.step() for _ in range(K)], sync, barrier, max_over_ranks)
                 s1 = block_stats(t1, batch * world * K, K)
                 s1.update({"roofline_frac": batch * alg / (s1["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                           "launch": "one launch of the step kernel per TTI on one stream (env.step() in a loop)"})
+                           "launch": "one launch of the step kernel per TTI on one stream (env.step() in a loop); option mix = "
+                                     f"{env.get_option('mix')}: a whole-batch step is one launch of mixed blocks -- one block per env of more "
+                                     "than 64 slice members, one per two envs of at most 64 -- resident in one round"})
                 extras["single_stream"] = s1
             # a learner in the loop: scores from the caller's stream, two halves alternating on their own streams
             env.set_partitions(1)
