@@ -26,6 +26,10 @@ is repeated until ~20 ms of stepping are sampled, the median block is reported (
   se_gather          ranenv_rollout in the SE gather mode (ranenv_set_se_mode: per-tile mean-SE sidecar + reads of the
                      allocated RBs only) -- as persistent work-queue launches, one per workgroup class --, with its own byte
                      model and bound
+  other_configs      (N = 1, default config only; --no-other-configs skips it) the other BASELINE configs as short blocks of the
+                     same K steps, each under the schedule ranenv_rollout picks for it: "1" = configs[1] (B 1024, MARR + round-robin),
+                     "4" = configs[4] (mult_slice_seq sweep, B 8192), "native" = the reference's own size (S 5 / U 25, B 16384, two
+                     envs per wave); value, ms_per_step, roofline_frac against each config's own algorithmic bytes
 """
 from __future__ import annotations
 
@@ -211,7 +215,7 @@ def gather_block(env, batch, world, steps, times, kms, parts, pmc):
     t = st["ms_per_step"] * 1e-3
     hbm_frac = b_env * batch / t / (HBM_PEAK_GBS * 1e9)
     out = dict(st)
-    persistent = kms["n_launches"] > 0 and kms.get("n_ttis", 0) == steps * kms["n_launches"] and steps > 10
+    persistent = bool(kms.get("persistent"))
     out.update({"bytes_per_env_step": b_env,
                 "bytes_model": "4*R (allocated RBs, each read once) + 8*U (sidecar row of per-UE mean SE) + 180*U + S*(85+8*Us) + 4",
                 "hbm_frac": hbm_frac,
@@ -230,6 +234,41 @@ def gather_block(env, batch, world, steps, times, kms, parts, pmc):
     else:
         out["bound"], out["frac"] = "hbm", hbm_frac
     return out
+
+
+def other_config_block(cfg, device, args, rank, se_pool, timing):
+    """One of the other BASELINE configs as a short block: its workload (the resident SE pool re-used where the shape matches),
+    warm-up, blocks of exactly K steps of ranenv_rollout under the schedule the library picks for it."""
+    import torch
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    sync, barrier, max_over_ranks = timing
+    K = args.steps
+    t0 = time.perf_counter()
+    wl, label = make_bench_workload(cfg, device, n_traces=args.traces, trace_len=args.trace_len, rank=rank, traffic=args.traffic,
+                                    se_pool=se_pool)
+    env = wl.env
+    parts = 3 if env.B >= 2048 else 1
+    env.set_partitions(parts)
+    env.reset()
+    env.rollout(max(1, args.warmup))
+    times = timed_blocks(lambda: env.rollout(K), sync, barrier, max_over_ranks)
+    st = block_stats(times, env.B * K, K)
+    alg = env.algorithmic_bytes_per_env_step("stream")
+    persistent, launches = env.get_option("last_rollout_persistent"), env.get_option("last_rollout_launches")
+    st.update({"workload": label, "batch": env.B, "n_slices": env.S, "n_ues": env.U, "n_rbs": env.R,
+               "algorithmic_bytes_per_env_step": alg,
+               "roofline_frac": env.B * alg / (st["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
+               "launch": (f"ranenv_rollout: {launches} persistent work-queue launch(es) for the K TTIs" if persistent else
+                          f"ranenv_rollout: {launches} launches of the step kernel over {parts} partition(s) for the K TTIs")
+                         + (", two envs per wave" if (env.U <= 32 and env.get_option("pack")) else ""),
+               "persistent": bool(persistent), "partitions": parts, "se_mode": "stream",
+               "setup_s": None})
+    sync()
+    env.close()
+    del wl, env
+    torch.cuda.empty_cache()
+    st["setup_s"] = round(time.perf_counter() - t0, 2)       # (workload build + warm-up + timed blocks: what the block adds to the run)
+    return st
 
 
 def main():
@@ -261,6 +300,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the se_gather variant (and its sidecar build)")
     ap.add_argument("--only-gather", action="store_true", help="profiling aid: run the se_gather variant only (the line's value "
                                                                 "is then the gather mode's, labelled so)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other_configs blocks (configs[1], configs[4], native size) the default N = 1 run appends")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="plumbing rehearsal of a multi-rank launch on a box with ONE GPU: every rank uses cuda:0 and the process "
                          "group is gloo (RCCL refuses two ranks on one device); the line is labelled a rehearsal, not a measurement")
@@ -329,6 +370,7 @@ def main():
         env.profile_begin()
         env.rollout(K)
         kms = env.profile_end()
+        kms["persistent"] = bool(env.get_option("last_rollout_persistent"))     # (reported by the library, not inferred)
         return times, kms
 
     times = kms = None
@@ -423,8 +465,19 @@ def main():
                 gathered = gm(local_metrics(env.reward, env.views(), env.done, K))
             env.set_se_mode("stream")
 
+    if world == 1 and args.config == 2 and args.batch is None and not args.no_other_configs and not args.only_gather:
+        sync()
+        pool = wl.se_pool
+        others = {}
+        for name, cfg in (("1", 1), ("4", 4), ("native", 5)):
+            try:
+                others[name] = other_config_block(cfg, device, args, rank, pool if cfg != 5 else None, (sync, barrier, max_over_ranks))
+            except (torch.OutOfMemoryError, _lib.RanEnvError) as e:
+                others[name] = {"skipped": str(e)}
+        extras["other_configs"] = others
+
     if rank == 0:
-        persistent = kms["n_launches"] > 0 and kms.get("n_ttis", 0) == K * kms["n_launches"] and K > 10    # every launch ran all K TTIs
+        persistent = bool(kms.get("persistent"))        # option last_rollout_persistent, read right behind the profiled call
         line = build_line(args, world, batch, label, (env.S, env.U, env.R),
                           env.algorithmic_bytes_per_env_step("gather" if args.only_gather else "stream"),
                           times, kms, parts, pmc, summarize(gathered.cpu()), persistent=persistent,

@@ -407,7 +407,13 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "persist_chunk" RANENV_PERSIST_CHUNK 10       TTIs of an env between two looks at the queues
  *   "persist_grid" RANENV_PERSIST_GRID  0         cap on the wave slots the persistent grids are sized for (0 = the occupancy
  *                                                 query x CUs); small values force hand-overs (tests)
- *   "persist_errors" (read only)                  waits of a persistent launch that gave up after ~1 s: 0 in every correct run
+ *   "persist_errors" (read only)                  persistent launches in which a wait gave up after ~1 s (0 in every correct run).  Such a launch
+ *                                                 drops its envs after their current chunk; the NEXT ranenv_rollout call sees the sticky error word
+ *                                                 (host-visible memory, no device sync), clears the queues, sets "persist" to 0 for the handle and
+ *                                                 fails with RANENV_E_STATE: the envs have advanced different numbers of TTIs, reset the batch
+ *   "persist_inject_abort" (no env variable)      test hook: 1 = the next persistent launch finds a wait already given up
+ *   "last_rollout_persistent" / "last_rollout_launches" (read only)   what the last ranenv_rollout call ran: 1 = persistent work-queue
+ *                                                 launches (else launches of <= 10 TTIs per partition); how many step-kernel launches it enqueued
  *   "persist_stat_keep" / "_push" / "_pop" / "_fresh" / "_idle_polls" (read only)   queue statistics of the persistent launches so far, summed over
  *                                                 classes and XCDs: chunk ends at which the workgroup kept its env, envs put down, envs taken
  *                                                 from a ready queue, envs taken fresh, spins on a slot whose pusher had not written yet

@@ -186,7 +186,7 @@ struct KP {
     struct PersistCtl *p_ctl;         // the class's counters and per-XCD queue heads
     unsigned long long *p_slots;      // [8][p_cap] queue entries {index + 1, item}
     int p_cap;                        // entries per queue (a power of two >= the batch)
-    int *p_err;                       // sticky error word of the handle (a wait gave up)
+    int *p_err;                       // sticky error word of the handle (a wait gave up), in host memory mapped for the device
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -545,7 +545,7 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
 // Loads: two 16-byte buffer loads per group with the whole offset in the VGPR (range-checked: a lane that has no group
 // left gets an offset past the descriptor and reads 0 without touching memory), two groups in flight per lane.
 // ---------------------------------------------------------------------------------------------
-template <int PACK = 1>
+template <int PACK = 1, int DEPTH = 2>     // DEPTH: 8-RB groups in flight per lane (1: the packed one-TTI build, which has no register to spare)
 DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c)
 {
     constexpr int OOB = 0x7ffffff0;
@@ -583,7 +583,7 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
         const int first = row_bytes_off + (base + g0 * 8) * 4;
         float q0[8], q1[8];
         ld8(q0, 0 < ng ? first : OOB);
-        ld8(q1, 1 < ng ? first + 32 : OOB);
+        if constexpr (DEPTH == 2) ld8(q1, 1 < ng ? first + 32 : OOB);
         double g[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) g[j] = 0.0;
@@ -591,13 +591,21 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
 #pragma unroll
             for (int j = 0; j < 8; j++) g[j] = fma((double)x[j], in(r0 + j) ? 1.0 : 0.0, g[j]);
         };
+        if constexpr (DEPTH == 2) {
 #pragma unroll 1
-        for (int i = 0; __builtin_amdgcn_ballot_w64(i < ng) != 0; i += 2) {
-            // a lane past its last group consumes zeros at RBs outside its range: +0.0
-            consume(q0, base + (g0 + i) * 8);
-            ld8(q0, i + 2 < ng ? first + (i + 2) * 32 : OOB);
-            consume(q1, base + (g0 + i + 1) * 8);
-            ld8(q1, i + 3 < ng ? first + (i + 3) * 32 : OOB);
+            for (int i = 0; __builtin_amdgcn_ballot_w64(i < ng) != 0; i += 2) {
+                // a lane past its last group consumes zeros at RBs outside its range: +0.0
+                consume(q0, base + (g0 + i) * 8);
+                ld8(q0, i + 2 < ng ? first + (i + 2) * 32 : OOB);
+                consume(q1, base + (g0 + i + 1) * 8);
+                ld8(q1, i + 3 < ng ? first + (i + 3) * 32 : OOB);
+            }
+        } else {
+#pragma unroll 1
+            for (int i = 0; __builtin_amdgcn_ballot_w64(i < ng) != 0; i += 1) {
+                consume(q0, base + (g0 + i) * 8);
+                ld8(q0, i + 1 < ng ? first + (i + 1) * 32 : OOB);
+            }
         }
         double gr = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
         if (last && tail > 0) {
@@ -699,9 +707,11 @@ struct SharedCore {
 };
 
 // Workgroup barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its global loads and
-// stores (__syncthreads() is a fence too: s_waitcnt vmcnt(0) before the barrier, i.e. the UE role's ~17 state stores would
-// have to be acknowledged before the obs role starts, and the SE loads requested ahead of the allocation would have to land
-// before its first exchange).  Nothing in the step kernel passes data between threads through global memory.
+// stores (the UE role's ~17 state stores need not be acknowledged before the obs role starts, and the SE loads requested ahead
+// of the allocation need not land before its first exchange).  Nothing in the step kernel passes data between threads through
+// global memory.  Where global memory IS handed over -- to the next TTI of the same workgroup without a warm entry, or to another
+// workgroup (persistent rollout) -- full_sync() below is used: __syncthreads() alone is NOT enough, the compiler's
+// workgroup-scope fence waits for lgkmcnt only (no vmcnt(0) outside tgsplit mode: ADVICE r4, seen in the shipped ISA).
 #ifndef RANENV_LDS_BARRIER
 #define RANENV_LDS_BARRIER 1
 #endif
@@ -717,9 +727,10 @@ DEVFN void wg_sync(const bool narrow = false)
     __syncthreads();
 #endif
 }
-DEVFN void full_sync(const bool narrow = false)      // __syncthreads(), or for a narrow wave: its own memory operations only
+DEVFN void full_sync(const bool narrow = false)      // every memory operation of this wave is complete (stores acknowledged by L2), then the barrier
 {
-    if (narrow) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); return; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (narrow) return;                              // (a narrow wave is a workgroup of its own)
     __syncthreads();
 }
 
@@ -730,12 +741,20 @@ template <int NP> DEVFN double *srow(SharedCore<NP> &sh, int s, int k) { return 
 // instead of a 64-bit address per array and lane (a VGPR pair and two vector adds each; the step kernel touches ~30 arrays).
 // The row address is made opaque where it is used: otherwise the optimiser forms array + row + lane once, as a 64-bit vector
 // value, and carries it from the load at the top of the step to the store at its end.
-// (PACK = 2: two envs per wave, lanes 0-31 / 32-63 -- the row differs between the halves, so it is an ordinary per-lane address)
+// (PACK = 2: two envs per wave, lanes 0-31 / 32-63 -- the row differs between the halves.  The array's base stays the scalar part
+// and row + lane offset go into the ONE 32-bit register of the saddr form: the host packs waves only while every array a packed
+// step addresses this way stays below 4 GB -- pack_fits_32 -- so the sum cannot wrap.  A 64-bit address per array and lane cost
+// the packed builds 13 spilled registers)
 template <int PACK = 1, typename T> DEVFN T &row_at(T *array, size_t row_bytes, unsigned lane_bytes)
 {
-    char *row = (char *)array + row_bytes;
-    if constexpr (PACK == 1) asm volatile("" : "+s"(row));
-    return *(T *)(row + lane_bytes);
+    if constexpr (PACK == 1) {
+        char *row = (char *)array + row_bytes;
+        asm volatile("" : "+s"(row));
+        return *(T *)(row + lane_bytes);
+    } else {
+        const unsigned off = (unsigned)row_bytes + lane_bytes;
+        return *(T *)((char *)array + off);
+    }
 }
 
 // Role (0).  Called by every thread of the workgroup (it contains barriers); `have` = this thread's UE is
@@ -973,6 +992,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // per-lane value that happens to be equal across a half, and the 16-lane slice groups are DPP rows 0 / 2 of the wave.
     static_assert(PACK == 1 || (PACK == 2 && MODE == MODE_STEP && !PERSIST), "packed waves: step launches only");
     constexpr int LW = WAVE / PACK;                  // lanes per env
+    constexpr int GDEPTH = (GATHER && NQ == 0) ? 1 : 2;      // gather builds: NQ = 0 asks for one 8-RB group in flight instead of two
     // MIX (ranenv_core_kernel_mixed): a two-wave block steps either one env of more than 64 slice members with both waves, or --
     // `narrow` -- two envs of at most 64, one per wave, each wave a workgroup of its own: its own LDS image, lanes counted from its
     // own first lane, no block barrier (wg_sync(narrow))
@@ -1184,7 +1204,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 #if RANENV_GATHER_STATE_FIRST
         rest_of_state();          // requested ahead of the gather: both latencies run together
 #endif
-        if (MODE == MODE_STEP) my_part = gather_part<PACK>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
+        if (MODE == MODE_STEP) my_part = gather_part<PACK, GDEPTH>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1 || RANENV_DIAG == 10
@@ -1649,8 +1669,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 
 // Several TTIs of one env in one launch (ranenv_rollout with a device policy, no episode end in between): the workgroup
 // steps its env again as soon as it is done, from the state it has just written (its own CU's L1 / L2 hold it), instead
-// of ending and being launched again.  Between TTIs: every store of the workgroup is out and visible to its other
-// waves (__syncthreads = wait for the wave's memory operations + barrier; the waves of a workgroup share their CU's L1).
+// of ending and being launched again.  Between TTIs without a warm entry: every store of the workgroup is out and visible to
+// its other waves (full_sync: explicit vmcnt(0) + barrier; the waves of a workgroup share their CU's L1).
 template <int MODE, int NQ, bool GATHER, int NP, bool MANY, int PACK = 1, bool MIX = false>      // MANY: the build for launches of more than one TTI
 DEVFN void step_loop(const KP &p)
 {
@@ -1761,7 +1781,7 @@ template <typename P> DEVFN int persist_try_pop(const P &p, const PersistLocal &
         PSTAT(4);
         if (spin > (1u << 22) || pq_ldi(&c->abort) != 0) {               // seconds on one slot: never in a correct run
             __hip_atomic_store(&c->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p.p_err) __hip_atomic_fetch_add(p.p_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.p_err) __hip_atomic_store(p.p_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (host memory: ranenv::h_perr)
             return PERSIST_EXIT;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -1778,7 +1798,7 @@ template <typename P> DEVFN int persist_try_pop(const P &p, const PersistLocal &
 template <typename P> DEVFN void persist_push(const P &p, const PersistLocal &pl, int item)
 {
     PersistCtl *c = p.p_ctl;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the workgroup's stores were waited for before the barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (every wave waited for its stores in front of the chunk-end barrier: full_sync)
     const unsigned idx = __hip_atomic_fetch_add(&c->q[pl.xcc].tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long *slot = p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (idx & (unsigned)(p.p_cap - 1));
     __hip_atomic_store(slot, ((unsigned long long)(idx + 1u) << 32) | (unsigned)item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1878,10 +1898,12 @@ DEVFN void persist_loop()
                 const bool ahead = RANENV_WARM_ENTRY != 0 && k + 1 < n;       // the next TTI of this chunk enters warm
                 (void)step_body<MODE_STEP, NQ, GATHER, NP, true>(*kc, cy, warm, e, &seq, se_ready, ahead);
                 se_ready = ahead;
-                if (k + 1 < n) { warm = RANENV_WARM_ENTRY != 0; if (warm) wg_sync(); else __syncthreads(); }
+                if (k + 1 < n) { warm = RANENV_WARM_ENTRY != 0; if (warm) wg_sync(); else full_sync(); }
             }
             done += n;
-            __syncthreads();                         // every wave's stores are acknowledged (vmcnt(0)) and every wave is here
+            // Hand-over point: EVERY wave waits for its own stores to be acknowledged by the XCD's L2 (explicit vmcnt(0): the
+            // barrier's fence does not), then all meet; only then may lane 0 publish the env to another workgroup.
+            full_sync();
             if (tid0 == 0) {
                 kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kc));
@@ -1922,17 +1944,27 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2,
 }
 
 // Sort the envs by the waves a compact step of theirs needs: class c = ceil(slice members of the env's scenario / 64) - 1.
-__global__ void __launch_bounds__(256) ranenv_persist_classify_kernel(const ranenv_episode *eps, const int32_t *members, int B, int n_class,
-                                                                      int one_class, int32_t *list, int32_t *count)
+// ONE workgroup (the counts are built in LDS: no memset in front, one launch in all).  `flag`: a device word that
+// ranenv_advance_kernel sets when an env has restarted -- without `force` the kernel does nothing unless the word is set, and it
+// clears it: an auto-reset loop in which no episode ended pays one empty launch, not a re-sort (and no host read-back of `done`).
+__global__ void __launch_bounds__(1024) ranenv_persist_classify_kernel(const ranenv_episode *eps, const int32_t *members, int B, int n_class,
+                                                                       int one_class, int32_t *list, int32_t *count, int *flag, int force)
 {
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= B) return;
-    const int m = members[eps[e].scenario];
-    int c = m <= 0 ? 0 : (m + WAVE - 1) / WAVE - 1;
-    c = c < n_class ? c : n_class - 1;
-    if (one_class) c = n_class - 1;               // a batch far below what the chip holds: idle waves cost nothing, a second launch does
-    const int pos = atomicAdd(&count[c], 1);
-    list[(size_t)c * B + pos] = e;
+    __shared__ int cnt[CORE_NT / WAVE];
+    if (!force && *flag == 0) return;                 // (uniform: every thread reads the word before thread 0 clears it, behind the barriers)
+    if (threadIdx.x < CORE_NT / WAVE) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = (int)threadIdx.x; e < B; e += (int)blockDim.x) {
+        const int m = members[eps[e].scenario];
+        int c = m <= 0 ? 0 : (m + WAVE - 1) / WAVE - 1;
+        c = c < n_class ? c : n_class - 1;
+        if (one_class) c = n_class - 1;           // a batch far below what the chip holds: idle waves cost nothing, a second launch does
+        const int pos = atomicAdd(&cnt[c], 1);
+        list[(size_t)c * B + pos] = e;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_class) count[threadIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x == 0) *flag = 0;
 }
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
 // 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 16 SE loads in flight per lane (8 until the build stopped hoisting
@@ -1967,8 +1999,9 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RA
 #define RANENV_GATHER_WAVES_PER_EU 5
 #endif
 // (the 16-wide row build keeps 16-entry rows of doubles alive in the allocation and does not fit 96 registers with the per-TTI loop
-// around it -- 2...10 spilled VGPRs, the only scratch in the library -- so it is built for 4 waves per SIMD: S or Us above 10 is
-// not a BASELINE size, and a spill in every TTI costs more than the fifth wave gains, profiles/r03_ab_log.txt)
+// around it -- 2...10 spilled VGPRs -- so it is built for 4 waves per SIMD: S or Us above 10 is not a BASELINE size, and a spill in
+// every TTI costs more than the fifth wave gains, profiles/r03_ab_log.txt.  No kernel of the library has scratch:
+// tests/test_kernel_resources.py reads the shipped code object's metadata)
 #define RANENV_WPE_NP(w) ((NP == 16 && MANY) ? 4 : (w))
 template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU), RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU))))
@@ -1993,7 +2026,7 @@ __global__ void __launch_bounds__(2 * WAVE) RANENV_CORE_ATTR ranenv_core_kernel_
 template <int NP, bool MANY, bool GATHER>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_packed(const KP p)
 {
-    step_loop<MODE_STEP, GATHER ? 1 : 2, GATHER, NP, MANY, 2>(p);
+    step_loop<MODE_STEP, GATHER ? (MANY ? 1 : 0) : 2, GATHER, NP, MANY, 2>(p);        // (one-TTI gather build: gather depth 1, it has no register to spare)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2292,6 +2325,7 @@ struct AdvanceArgs {
     const float *obs_inter, *obs_intra, *head_obs; float *term_inter, *term_intra, *term_head;
     int n_inter, n_intra, n_head;
     int e0;                                       // first env of this launch (batch partitions)
+    int *cls_flag;                                // set when an env restarts: the class lists of the mixed / persistent launches are stale
     const double *acc; double *ep_acc; int32_t *ep_n; int ep_slots;   // episode metrics: running sums -> per-episode log
 };
 
@@ -2322,6 +2356,7 @@ __global__ void __launch_bounds__(64) ranenv_advance_kernel(const AdvanceArgs a)
         }
         a.episode_no[e] = next; a.reset_count[e] = cnt;
         a.episodes[e] = a.table[next - a.table_first];
+        if (a.cls_flag) *a.cls_flag = 1;
     }
 }
 
@@ -2382,8 +2417,14 @@ struct ranenv {
     int persist_grid = 0;          // experiment: cap on the workgroups of a persistent launch, in wave slots (0 = what the chip holds)
     std::vector<int32_t> members_host; int32_t *d_members = nullptr;      // [NS] UEs in slices per scenario
     int32_t *d_plist = nullptr, *d_pcount = nullptr; PersistCtl *d_pctl = nullptr; unsigned long long *d_pslots = nullptr;
-    int *d_perr = nullptr; int p_nclass = 0, p_cap = 0;
+    int p_nclass = 0, p_cap = 0;
     std::vector<int32_t> pcount_host; bool pclass_dirty = true, pcount_host_stale = true;
+    bool pclass_maybe = false;     // an auto-reset ran since the lists were built: they are stale IF an env restarted (the device knows:
+    int *d_cls_flag = nullptr;     // ... this word, set by ranenv_advance_kernel, tested and cleared by the classify kernel)
+    int *h_perr = nullptr;         // sticky error word of the persistent launches, in host memory the device can write (a wait gave up)
+    int perr_seen = 0;             // ... what of it has been reported
+    int persist_inject = 0;        // test hook (option "persist_inject_abort"): the next persistent launch finds its abort word set
+    int last_rollout_persistent = 0, last_rollout_launches = 0;   // what the last ranenv_rollout call ran (read-only options)
     int p_wave_slots[2] = {0, 0};  // wave slots per CU of the persistent kernel (streaming, gather build), from the occupancy query
     long long prof_env_ttis = 0;   // env-TTIs covered by the launches timed since ranenv_profile_begin
     int fuse = 0;                  // TTIs per launch inside ranenv_rollout: 0 = chosen per rollout, n = at most n (1 = off)
@@ -2524,6 +2565,18 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
 int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts);
 bool persist_tiny(ranenv_handle h);
 
+// Packed waves address a per-env row as (uniform array base) + (32-bit row + lane offset), see row_at<2>: every array they
+// address that way must stay below 4 GB.  True for every size a packed step makes sense at (the reference's: megabytes); a handle
+// with pools beyond that steps one env per wave.
+bool pack_fits_32(ranenv_handle h)
+{
+    const unsigned long long lim = 1ull << 32, B = (unsigned long long)h->cfg.batch, U = (unsigned long long)h->cfg.n_ues,
+                             S = (unsigned long long)h->cfg.n_slices, NS = (unsigned long long)h->cfg.n_scenarios,
+                             D = (unsigned long long)h->cfg.hist_depth, W = 2ull * h->cfg.max_ues_slice + 9ull;
+    return (unsigned long long)N_TUE * NS * U * 4 < lim && B * U * 8 < lim && B * D * U * 4 < lim && NS * S * 32 < lim &&
+           B * S * W * 4 < lim && (unsigned long long)h->trf_rows_n * U * 4 < lim && (unsigned long long)h->se_tiles_n * U * 8 < lim;
+}
+
 // One launch of the step kernel for envs [e0, e0 + n) on `stream` (+ the head kernel when bound).
 template <int MODE>
 hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t stream)
@@ -2588,7 +2641,7 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
             return hipGetLastError();
         }
         // packed waves: two envs per wave for envs of <= 32 UEs / <= 8 slices (see ranenv_core_kernel_packed)
-        if (h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr) {
+        if (h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr && pack_fits_32(h)) {
             KP kq = kp;
             kq.late = 0;
             const dim3 pgrid((unsigned)(n / 2)), pblock((unsigned)WAVE);
@@ -2728,6 +2781,7 @@ AdvanceArgs advance_args(ranenv_handle h, const uint8_t *dev_done, float *obs_in
     a.term_inter = obs_inter ? term_obs_inter : nullptr; a.term_intra = obs_intra ? term_obs_intra : nullptr; a.term_head = term_obs_head;
     a.n_inter = S * 10; a.n_intra = S * (2 * Us + 9); a.n_head = S * 10;
     a.e0 = 0;
+    a.cls_flag = h->d_cls_flag;
     a.acc = h->kp.acc; a.ep_acc = h->d_ep_acc; a.ep_n = h->d_ep_n; a.ep_slots = h->ep_slots;
     return a;
 }
@@ -2787,7 +2841,18 @@ void launch_persist(int np, const KP &kp, dim3 grid, dim3 block, hipStream_t str
     }
 }
 
+bool stream_capturing(hipStream_t stream)      // (an error of the query itself counts as "capturing": the careful path)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 // The buffers of the work queues (once per handle) and, whenever scenarios / episodes changed, the envs sorted by class.
+// Three states of the lists: clean; `pclass_dirty` (the host changed scenarios / episodes, or followed an episode end itself: re-sort);
+// `pclass_maybe` (an auto-reset ran: re-sort only if the device's flag says an env restarted -- the host does not read `done`).
+// On a CAPTURING stream the sort is enqueued unconditionally and the host's flags stay as they are: what a replay of the graph
+// finds in the episode descriptors is not what the host knows now (set_episodes / reset / an eager auto-reset between replays).
 int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
 {
     const int B = h->cfg.batch, NC = h->nt / WAVE;
@@ -2796,17 +2861,25 @@ int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
         while (cap < B) cap <<= 1;
         h->p_nclass = NC; h->p_cap = cap;
         if (dev_alloc(h, &h->d_plist, (size_t)NC * B) != RANENV_OK || dev_alloc(h, &h->d_pcount, (size_t)NC) != RANENV_OK ||
-            dev_alloc(h, &h->d_pctl, (size_t)NC) != RANENV_OK || dev_alloc(h, &h->d_pslots, (size_t)NC * 8 * (size_t)cap) != RANENV_OK ||
-            dev_alloc(h, &h->d_perr, 1) != RANENV_OK)
+            dev_alloc(h, &h->d_pctl, (size_t)NC) != RANENV_OK || dev_alloc(h, &h->d_pslots, (size_t)NC * 8 * (size_t)cap) != RANENV_OK)
             return RANENV_E_NOMEM;
+        // the sticky error word lives in host memory the device can write: the host looks at it without a device sync
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_perr, sizeof(int), hipHostMallocMapped));
+        *h->h_perr = 0;
         h->pcount_host.assign((size_t)NC, 0);
         h->pclass_dirty = true;
     }
-    if (h->pclass_dirty) {
-        HIP_TRY(h, hipMemsetAsync(h->d_pcount, 0, sizeof(int32_t) * (size_t)NC, stream));
-        hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, h->d_episodes,
-                           h->d_members, B, NC, (persist_tiny(h) && h->mix != 2) ? 1 : 0, h->d_plist, h->d_pcount);
-        h->pclass_dirty = false; h->pcount_host_stale = true;
+    const bool capturing = stream_capturing(stream);
+    if (capturing && need_host_counts) return fail(h, RANENV_E_STATE, "a persistent rollout reads its class counts back: not inside a stream capture");
+    const int one_class = (persist_tiny(h) && h->mix != 2) ? 1 : 0;
+    if (h->pclass_dirty || capturing) {
+        hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3(1), dim3(1024), 0, stream, h->d_episodes, h->d_members, B, NC, one_class,
+                           h->d_plist, h->d_pcount, h->d_cls_flag, 1);
+        if (!capturing) { h->pclass_dirty = false; h->pclass_maybe = false; h->pcount_host_stale = true; }
+    } else if (h->pclass_maybe) {
+        hipLaunchKernelGGL(ranenv_persist_classify_kernel, dim3(1), dim3(1024), 0, stream, h->d_episodes, h->d_members, B, NC, one_class,
+                           h->d_plist, h->d_pcount, h->d_cls_flag, 0);
+        h->pclass_maybe = false; h->pcount_host_stale = true;
     }
     if (need_host_counts && h->pcount_host_stale) {       // (the persistent launches size their grids by them; mixed launches read them on the device)
         HIP_TRY(h, hipMemcpyAsync(h->pcount_host.data(), h->d_pcount, sizeof(int32_t) * (size_t)NC, hipMemcpyDeviceToHost, stream));
@@ -2814,6 +2887,24 @@ int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
         h->pcount_host_stale = false;
     }
     return RANENV_OK;
+}
+
+// A wait inside a persistent launch gave up (PersistCtl::abort: every workgroup of that class then drops its env after the
+// current chunk, so the envs have advanced different numbers of TTIs).  Seen through the host-visible error word at the next call:
+// the queues and cursors are cleared, the persistent rollout is switched off for this handle (the launch-per-chunk rollout
+// takes over) and the call fails -- the batch has to be reset.
+int persist_check_errors(ranenv_handle h)
+{
+    if (!h->h_perr || *(volatile int *)h->h_perr == 0) return RANENV_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemset(h->d_pctl, 0, sizeof(PersistCtl) * (size_t)h->p_nclass));
+    HIP_TRY(h, hipMemset(h->d_pslots, 0, sizeof(unsigned long long) * (size_t)h->p_nclass * 8 * (size_t)h->p_cap));
+    *(volatile int *)h->h_perr = 0;
+    h->perr_seen++;
+    h->persist = 0;
+    return fail(h, RANENV_E_STATE, "a persistent rollout launch gave up waiting on its work queue (sticky error word): the envs of the batch "
+                "have advanced different numbers of TTIs -- reset the batch; the persistent rollout is now off for this handle "
+                "(option persist = 0), its queues were cleared");
 }
 
 // One persistent launch per non-empty class for `n_tti` TTIs of every env: the class with the widest blocks on the caller's
@@ -2824,7 +2915,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
     const int B = h->cfg.batch, NC = h->p_nclass;
     const bool gather = h->se_mode == RANENV_SE_GATHER;
     kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0;
-    kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->d_perr;
+    kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->h_perr;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
         kp.se_mean_pool = h->d_se_mean; kp.se_rp = h->se_rp;
@@ -2868,6 +2959,11 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         if (tiny && g == n) kc.p_chunk = n_tti > 1 ? n_tti : 1;
         kc.p_list = h->d_plist + (size_t)c * B; kc.p_count = n; kc.p_ctl = h->d_pctl + c;
         kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
+        if (h->persist_inject) {                   // test hook: this launch finds a wait already given up
+            const int one = 1;
+            HIP_TRY(h, hipMemcpyAsync(&kc.p_ctl->abort, &one, sizeof(int), hipMemcpyHostToDevice, s));
+            *(volatile int *)h->h_perr = 1;
+        }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (h->prof_on) {
             while (h->prof_ev.size() < h->prof_used + 2) {
@@ -2892,6 +2988,8 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         k++;
     }
     for (int j = 1; j < k; j++) HIP_TRY(h, hipStreamWaitEvent(stream, h->part_done[(size_t)j], 0));
+    h->persist_inject = 0;
+    h->last_rollout_launches += k;
     e = hipGetLastError();
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout launch: %s", hipGetErrorString(e));
     if (h->cfg.flags & RANENV_F_SYNC_CHECK) HIP_TRY(h, hipStreamSynchronize(stream));
@@ -2920,6 +3018,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
     if (k == "pack") { h->pack = v != 0; return RANENV_OK; }
     if (k == "mix") { h->mix = v < 0 ? 0 : (v > 2 ? 2 : (int)v); h->pclass_dirty = true; return RANENV_OK; }
+    if (k == "persist_inject_abort") { h->persist_inject = v != 0 ? 1 : 0; return RANENV_OK; }     // test hook, see persist_check_errors
     if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9') {
         const size_t i = (size_t)(k[10] - '0');
         if (h->fuse_first.size() <= i) h->fuse_first.resize(i + 1, 0);
@@ -3007,7 +3106,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
     ALLOC(kp.st.next_scores, B * S);
-    ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B); ALLOC(h->d_members, NS);
+    ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B); ALLOC(h->d_members, NS); ALLOC(h->d_cls_flag, 1);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
     kp.episodes = h->d_episodes;
@@ -3070,11 +3169,13 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
         }
         *value = tot;
     }
-    else if (k == "persist_errors") {          // sticky: waits of a persistent launch that gave up (0 in every correct run)
+    else if (k == "persist_errors") {          // persistent launches that gave up a wait: reported so far + pending (0 in every correct run)
         int v = 0;
-        if (h->d_perr) { HIP_TRY(h, hipSetDevice(h->cfg.device)); HIP_TRY(h, hipDeviceSynchronize()); HIP_TRY(h, hipMemcpy(&v, h->d_perr, sizeof(int), hipMemcpyDeviceToHost)); }
-        *value = v;
+        if (h->h_perr) { HIP_TRY(h, hipSetDevice(h->cfg.device)); HIP_TRY(h, hipDeviceSynchronize()); v = *(volatile int *)h->h_perr != 0 ? 1 : 0; }
+        *value = h->perr_seen + v;
     }
+    else if (k == "last_rollout_persistent") *value = h->last_rollout_persistent;      // what the last ranenv_rollout call ran:
+    else if (k == "last_rollout_launches") *value = h->last_rollout_launches;          // 1 = persistent work-queue launches; step-kernel launches enqueued
     else if (k.rfind("fuse_first", 0) == 0 && k.size() == 11 && k[10] >= '0' && k[10] <= '9')
         *value = (size_t)(k[10] - '0') < h->fuse_first.size() ? h->fuse_first[(size_t)(k[10] - '0')] : 0;
     else return fail(h, RANENV_E_INVALID, "unknown option '%s'", key);
@@ -3092,6 +3193,7 @@ int ranenv_destroy(ranenv_handle h)
     for (auto &st : h->part_stream) if (st) (void)hipStreamDestroy(st);
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     for (void *p : h->allocs) (void)hipFree(p);
+    if (h->h_perr) (void)hipHostFree(h->h_perr);
     delete h;
     return RANENV_OK;
 }
@@ -3576,10 +3678,13 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     const bool have_se = h->kp.se_pool != nullptr || (h->se_mode == RANENV_SE_GATHER && h->d_se_mean != nullptr);
     if (!have_se || (!h->kp.trf_pool && !h->kp.trf_gen)) return fail(h, RANENV_E_STATE, "a rollout replays the bound SE pool and traffic pool / generator");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    rc = persist_check_errors(h);                  // (of the persistent launches of earlier calls that have completed)
+    if (rc != RANENV_OK) return rc;
     KP kp = h->kp;
     kp.env_mask = nullptr; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
     kp.dense = nullptr; kp.obs_inter = obs_inter; kp.obs_intra = obs_intra; kp.reward = reward; kp.done = done;
     hipStream_t stream = (hipStream_t)stream_;
+    h->last_rollout_persistent = 0; h->last_rollout_launches = 0;
     finalize_kp(h, kp);
     rc = compact_for(h, kp, stream, &kp.compact);
     if (rc != RANENV_OK) return rc;
@@ -3613,7 +3718,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // (auto: not when episodes end at many different TTIs inside this call -- per-env episode lengths, envs reset at different times:
     // every episode end ends the persistent launches, re-sorts the envs and reads the class counts back; the launch-per-chunk
     // rollout follows the ends per partition without a host sync)
-    bool persist_ok = persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0;
+    bool persist_ok = persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0 &&
+                      !stream_capturing(stream);      // (it reads the class counts back)
     if (persist_ok && h->persist < 0 && follow) {
         std::vector<int> ends;
         for (int b = 0; b < h->cfg.batch && ends.size() <= 2; b++) {
@@ -3623,6 +3729,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
         if (ends.size() > 2) persist_ok = false;
     }
     if (persist_ok) {
+        h->last_rollout_persistent = 1;
         for (int done_ttis = 0; done_ttis < n_steps;) {
             int n_tti = n_steps - done_ttis;
             if (follow) {
@@ -3697,6 +3804,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
             if (n_tti == 0) return hipSuccess;                                    // this partition is through
             KP kpk = kp;
             kpk.n_tti = n_tti;
+            h->last_rollout_launches++;
             hipError_t le = launch_range<MODE_STEP>(h, kpk, e0, n, s);
             if (le != hipSuccess || !follow) return le;
             bool any = false;
@@ -3852,7 +3960,7 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
     const AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
-    h->pclass_dirty = true;                      // (scenarios of the restarted envs)
+    h->pclass_maybe = true;                      // (scenarios of the restarted envs, if any: the advance kernel sets the device's flag)
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;
@@ -3882,7 +3990,7 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
     const int e0 = h->part_lo[(size_t)part], n = h->part_lo[(size_t)part + 1] - e0;
     AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
     a.e0 = e0;
-    h->pclass_dirty = true;
+    h->pclass_maybe = true;
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)n), dim3(64), 0, ps, a);
     KP kp = h->kp;
     kp.env_mask = h->d_ar_mask; kp.se_tiles = nullptr; kp.scores = nullptr; kp.intra = nullptr; kp.traffic_bits = nullptr;

@@ -268,25 +268,26 @@ def _compare_with_oracle(env, oenvs, max_pkts, where):
         np.testing.assert_allclose(rw[b], oo["reward"], rtol=0, atol=REW_TOL, err_msg=str((where, b)))
 
 
-@pytest.mark.parametrize("se_mode", ["stream", "gather"])
-def test_config2_headline_schedule_vs_oracle(se_mode):
-    _need_gpu()
+def _partition_bounds(B, parts, unit=1):
+    """ranenv_set_partitions' cut of the batch (an even batch into even ranges where possible: unit 2)."""
+    base, rem = divmod(B // unit, parts)
+    lo = [0]
+    for k in range(parts):
+        lo.append(lo[-1] + unit * (base + (1 if k < rem else 0)))
+    return lo
+
+
+def _mirror_rollouts_with_the_oracle(wl, sample, calls, se_mode, where, after_call=None):
+    """The bench schedule of `wl` (whatever its options select) against the CPU oracle: the envs in `sample` are mirrored by
+    pyoracle.OracleEnv under the workload's own device policy (MARR agents/marr.py:40-47 / MAPF agents/mapf.py:41-111, scores from the
+    oracle's own state, simu.py:555-566) and intra-slice scheduler (agents/common.py:508-636) and compared after every
+    ranenv_rollout call of `calls`: integers exact, observations 1e-5, rewards 1e-9.  after_call(k): extra assertions on the launch."""
     from oracle import pyoracle
-    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
-    wl, label = make_bench_workload(2, torch.device("cuda", 0), n_traces=64, trace_len=80)
     env = wl.env
-    assert env.B == 4096 and "MAPF" in label and wl.policy == 2 and wl.intra == 1
-    env.set_se_mode(se_mode)
-    env.set_partitions(3)
-    env.set_option("compact", 1); env.set_option("fuse", 0)      # the headline's settings, whatever knob the suite runs under
-    for i in range(3):
-        env.set_option(f"fuse_first{i}", 0)
-    sample, members = _headline_sample(wl)
-    assert len(sample) >= 32 and (members[sample] <= 64).sum() >= 12 and (members[sample] > 64).sum() >= 12
     S, U, R = env.S, env.U, env.R
     cfg = pyoracle.make_cfg(S, U, R, env.G, env.Us, bandwidth_hz=env.bandwidth_hz, max_age_cap=env.max_age_cap, max_steps=env.max_steps)
     eps, L = env.episodes, wl.trace_len
-    tiles = sorted({int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L) for b in sample for t in range(sum(ROLLOUT_CALLS) + 1)})
+    tiles = sorted({int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L) for b in sample for t in range(sum(calls) + 1)})
     tpos = {t: i for i, t in enumerate(tiles)}
     se_host = wl.se_pool[torch.as_tensor(tiles, device=env.device)].transpose(1, 2).contiguous().cpu().numpy()   # oracle layout [U][R]
     trf_host = wl.traffic_pool.cpu().numpy().astype(np.float64)
@@ -299,29 +300,152 @@ def test_config2_headline_schedule_vs_oracle(se_mode):
         oenvs[b] = o
     env.reset()
     max_pkts = {b: np.asarray(wl.tables.ue_max_pkts)[int(wl.scenario[b])] for b in sample}
+    score = (lambda o: o.policy_mapf()) if wl.policy == 2 else (lambda o: o.policy_marr())
     t = 0
-    for k in ROLLOUT_CALLS:
+    for k in calls:
         env.rollout(k)
+        if after_call is not None:
+            after_call(k)
         for _ in range(k):
             for b, o in oenvs.items():
-                o.step(o.policy_mapf(), intra, se_host[tpos[int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)]],
+                o.step(score(o), intra, se_host[tpos[int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)]],
                        trf_host[int(eps["trf_base"][b] + (eps["trf_offset"][b] + t) % L)])
             t += 1
         torch.cuda.synchronize()
-        _compare_with_oracle(env, oenvs, max_pkts, (se_mode, "after TTI", t))
-    assert int(env.views()["step_number"].min()) == t == sum(ROLLOUT_CALLS)
+        _compare_with_oracle(env, oenvs, max_pkts, (where, se_mode, "after TTI", t))
+    assert int(env.views()["step_number"].min()) == t == sum(calls)
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_config2_headline_schedule_vs_oracle(se_mode):
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(2, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    env = wl.env
+    assert env.B == 4096 and "MAPF" in label and wl.policy == 2 and wl.intra == 1
+    env.set_se_mode(se_mode)
+    env.set_partitions(3)
+    env.set_option("compact", 1); env.set_option("fuse", 0)      # the headline's settings, whatever knob the suite runs under
+    for i in range(3):
+        env.set_option(f"fuse_first{i}", 0)
+    sample, members = _headline_sample(wl)
+    assert len(sample) >= 32 and (members[sample] <= 64).sum() >= 12 and (members[sample] > 64).sum() >= 12
+    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[2]")
     env.close()
 
 
-def test_config2_headline_schedule_across_an_episode_end_vs_oracle():
-    """The same schedule with device auto-reset: every env's episode (37 TTIs here) ends inside the rollouts, the advance +
-    RESET launches follow that TTI on the partition's own stream, the fused launches end there."""
+# ------------------------------------------------------------------------------------------------------------------
+# The OTHER benchmarked schedules against the oracle at their bench size: until round 5 they met the oracle
+# in small batches only and their bench-size runs were compared with another build of the same kernel.
+# ------------------------------------------------------------------------------------------------------------------
+def _bench_options(env):
+    """the defaults bench.py runs under, whatever knob the suite runs under"""
+    for k, v in (("compact", 1), ("fuse", 0), ("persist", -1), ("persist_chunk", 10), ("persist_grid", 0), ("pack", 1), ("mix", 1), ("late", 0)):
+        env.set_option(k, v)
+    for i in range(3):
+        env.set_option(f"fuse_first{i}", 0)
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_config1_bench_schedule_vs_oracle(se_mode):
+    """BASELINE configs[1] (B 1024, MARR + round-robin) as bench.py runs it: a batch at <= 2 waves per SIMD, so ranenv_rollout is ONE
+    persistent launch of one chunk -- streaming: ranenv_persist_kernel_tiny, the whole SE row in flight and the next TTI's tile
+    requested a TTI ahead.  The test fails if the auto rule stops selecting that launch."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(1, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    env = wl.env
+    assert env.B == 1024 and "round-robin" in label and wl.policy == 1 and wl.intra == 0
+    env.set_se_mode(se_mode)
+    _bench_options(env)
+    members = (wl.tables.ue_slice[wl.scenario] >= 0).sum(axis=1)
+    small, big = np.flatnonzero(members <= 64), np.flatnonzero(members > 64)
+    sample = sorted(set(small[np.linspace(0, len(small) - 1, 18).astype(int)].tolist() + big[np.linspace(0, len(big) - 1, 18).astype(int)].tolist()
+                        + [0, 1023]))
+    assert len(sample) >= 32
+
+    launches = []
+
+    def one_persistent_launch(k):
+        assert env.get_option("last_rollout_persistent") == 1, "configs[1] no longer runs the persistent launch"
+        launches.append(env.get_option("last_rollout_launches"))
+        assert launches[-1] == 1, launches              # one class, one launch for all k TTIs
+    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[1]", after_call=one_persistent_launch)
+    # ... and by the dispatch's own bookkeeping: one launch covered all the TTIs of a call
+    env.profile_begin(); env.rollout(13); kms = env.profile_end()
+    assert kms["n_launches"] == 1 and kms["n_ttis"] == 13 and kms["n_env_ttis"] == 13 * 1024, kms
+    env.close()
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_config4_bench_schedule_vs_oracle(se_mode):
+    """BASELINE configs[4] (mult_slice_seq sweep, B 8192, mixed active-slice masks) as bench.py runs it: three partitions, launches of up
+    to 10 TTIs (streaming) / persistent launches per class (gather).  Mirrored: an env of each of the 10 scenario groups from every
+    partition, and the partitions' first and last envs."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(4, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    env = wl.env
+    assert env.B == 8192 and "mult_slice_seq" in label
+    env.set_se_mode(se_mode)
+    env.set_partitions(3)
+    _bench_options(env)
+    lo = _partition_bounds(8192, 3, unit=2)
+    sample = []
+    for k in range(3):
+        idx = np.arange(lo[k], lo[k + 1])
+        for g in range(10):
+            sample.append(int(idx[wl.scenario[idx] == g][k]))          # (a different env of the group in every partition)
+        sample += [int(idx[0]), int(idx[-1])]
+    sample = sorted(set(sample))
+    assert len(sample) >= 32 and set(wl.scenario[sample].tolist()) == set(range(10))
+    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[4]")
+    assert env.get_option("last_rollout_persistent") == (1 if se_mode == "gather" else 0)
+    env.close()
+
+
+def _native_sample(B, parts):
+    """both envs of several packed waves (pairs 2i, 2i + 1) of every partition, the partitions' edges included"""
+    lo = _partition_bounds(B, parts, unit=2)
+    sample = []
+    for k in range(parts):
+        n = lo[k + 1] - lo[k]
+        for off in (0, 2, n // 3 & ~1, n // 2 & ~1, n - 4, n - 2):
+            sample += [lo[k] + off, lo[k] + off + 1]
+    return sorted(set(sample)), lo
+
+
+@pytest.mark.parametrize("se_mode", ["stream", "gather"])
+def test_native_size_bench_schedule_vs_oracle(se_mode):
+    """The reference's own size (env_config/mult_slice.yml:2-14, agents/ib_sched.py:50,56: what every reference agent trains at) as
+    bench.py --config native runs it: B 16 384, three partitions, TWO envs per wave (ranenv_core_kernel_packed), MAPF + PF."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, label = make_bench_workload(5, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    env = wl.env
+    assert env.B == 16384 and (env.S, env.U, env.R, env.G) == (5, 25, 135, 5)
+    env.set_se_mode(se_mode)
+    env.set_partitions(3)
+    _bench_options(env)
+    sample, lo = _native_sample(16384, 3)
+    assert lo == [0, 5462, 10924, 16384] and len(sample) >= 32
+    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "native")
+    assert env.get_option("last_rollout_persistent") == 0 and env.get_option("pack") == 1
+    env.close()
+
+
+@pytest.mark.parametrize("config", [2, 5])
+def test_bench_schedule_across_an_episode_end_vs_oracle(config):
+    """The headline schedule (configs[2]) and the native-size one (two envs per wave) with device auto-reset: every env's episode (37
+    TTIs here) ends inside the rollouts, the advance + RESET launches follow that TTI on the partition's own stream, the fused
+    launches end there."""
     _need_gpu()
     from oracle import pyoracle
     from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
-    wl, _ = make_bench_workload(2, torch.device("cuda", 0), n_traces=64, trace_len=80)
+    wl, _ = make_bench_workload(config, torch.device("cuda", 0), n_traces=64, trace_len=80)
     env, tabs = wl.env, wl.tables
     env.set_partitions(3)
+    _bench_options(env)
     S, U, R, L, B = env.S, env.U, env.R, wl.trace_len, env.B
     n_ep, first, ep_len = 50, 0, 37
     ep_no = np.arange(first, first + n_ep)
@@ -333,12 +457,14 @@ def test_config2_headline_schedule_across_an_episode_end_vs_oracle():
     tab = env.episode_table
     scen_of = lambda ep: int(tab[ep - first]["scenario"])
     members = np.array([(tabs.ue_slice[scen_of(int(ep))] >= 0).sum() for ep in start])
-    base, rem = divmod(B, 3)
-    sample = []
-    for k in range(3):
-        lo = k * base + min(k, rem)
-        idx = np.arange(lo, lo + base + (1 if k < rem else 0))
-        sample += idx[members[idx] <= 64][:5].tolist() + idx[members[idx] > 64][:5].tolist() + [int(idx[-1])]
+    if config == 5:
+        sample, _ = _native_sample(B, 3)
+    else:
+        lo = _partition_bounds(B, 3, unit=2)
+        sample = []
+        for k in range(3):
+            idx = np.arange(lo[k], lo[k + 1])
+            sample += idx[members[idx] <= 64][:5].tolist() + idx[members[idx] > 64][:5].tolist() + [int(idx[-1])]
     cfg = pyoracle.make_cfg(S, U, R, env.G, env.Us, bandwidth_hz=env.bandwidth_hz, max_age_cap=env.max_age_cap, max_steps=10 ** 6)
     se_pool, trf_host = wl.se_pool, wl.traffic_pool.cpu().numpy().astype(np.float64)
     tile_cache = {}

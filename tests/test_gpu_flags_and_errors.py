@@ -434,3 +434,133 @@ def test_partitioned_step_survives_stream_capture():
     assert int(outs[1][3].min()) == 7
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def _captured_step_graph(env, dev, n=1):
+    s = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode="relaxed"):
+            for _ in range(n):
+                env.step()
+    return g
+
+
+def test_graph_captured_mixed_step_follows_scenario_changes_between_replays():
+    """a whole-batch step of two-wave workgroups runs as MIXED blocks (one block per env of more than 64 slice members,
+    one per two envs of at most 64) from class lists that the HOST re-sorts when it knows the scenarios changed.  A graph
+    captured while the lists were clean holds no sort; when set_episodes / reset change the envs' scenarios between replays the
+    replayed launch would step an env that now has more than 64 slice members with ONE narrow wave (lanes >= 64 never stepped).
+    Inside a capture the sort is therefore always enqueued in front of the mixed launch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    B = 512
+    outs = []
+    for mode in ("eager", "graph"):
+        wl = make_mult_slice_workload(B, dev, n_scenarios=32, n_traces=8, trace_len=16, max_steps=1000)
+        env = wl.env
+        env.set_option("mix", 2); env.set_option("compact", 1)          # mixed blocks also for a batch that fits the chip
+        members = (wl.tables.ue_slice >= 0).sum(axis=1)
+        assert (members > 64).any() and (members <= 64).any()
+        env.reset(); env.step(); torch.cuda.synchronize()
+        g = _captured_step_graph(env, dev) if mode == "graph" else None
+        stages = []
+        for stage in range(2):
+            if stage == 1:
+                # every env moves to a scenario of the OTHER class where there is one
+                wide = np.flatnonzero(members > 64); narrow = np.flatnonzero(members <= 64)
+                cur = wl.scenario
+                new = np.where(members[cur] > 64, narrow[np.arange(B) % len(narrow)], wide[np.arange(B) % len(wide)])
+                env.set_episodes(scenario=new, se_base=wl.se_trace * wl.trace_len, se_len=wl.trace_len, se_offset=wl.se_offset,
+                                 trf_base=new * wl.trace_len, trf_len=wl.trace_len, trf_offset=0)
+                env.reset()
+            for _ in range(4):
+                if g is not None:
+                    g.replay()
+                else:
+                    env.step()
+            torch.cuda.synchronize()
+            v = env.views()
+            stages.append((env.obs_inter.clone(), env.obs_intra.clone(), env.reward.clone(), v["queue_pkts"].clone(),
+                           v["pkt_effective_thr"].clone(), v["rb_count"].clone(), v["step_number"].clone()))
+        outs.append(stages)
+        env.close()
+    for stage in range(2):
+        for a, b in zip(outs[0][stage], outs[1][stage]):
+            assert torch.equal(a, b), stage
+
+
+def test_autoreset_loop_resorts_the_mixed_blocks_only_when_an_env_restarted():
+    """The same lists in an eager auto-reset loop: the advance kernel raises a device flag when an env restarts, the (one-block)
+    sort in front of the next mixed launch looks at it -- no host read-back of `done`.  Episodes of 5 TTIs whose scenarios change
+    class at every restart, against the same loop with mixed blocks off."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    B, n_ep, L = 300, 12, 16
+    outs = []
+    for mix in (0, 2):
+        wl = make_mult_slice_workload(B, dev, n_scenarios=32, n_traces=8, trace_len=L, max_steps=1000)
+        env = wl.env
+        env.set_option("mix", mix); env.set_option("compact", 1)
+        members = (wl.tables.ue_slice >= 0).sum(axis=1)
+        wide = np.flatnonzero(members > 64); narrow = np.flatnonzero(members <= 64)
+        ep = np.arange(n_ep)
+        scen = np.where(ep % 2 == 0, wide[ep % len(wide)], narrow[ep % len(narrow)])        # alternating classes
+        env.set_episode_table(scenario=scen, se_base=(ep % 8) * L, se_len=L, se_offset=ep % L, trf_base=scen * L, trf_len=L, trf_offset=(ep * 3) % L)
+        env.set_max_steps(5 + (np.arange(B) % 3))
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep)
+        env.reset()
+        trace = []
+        for t in range(23):
+            env.step()
+            trace.append((env.reward.clone(), env.done.clone(), env.views()["queue_pkts"].clone(), env.views()["episode_number"].clone()))
+        torch.cuda.synchronize()
+        outs.append(trace)
+        env.close()
+    for t, (a, b) in enumerate(zip(*outs)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), t
+    assert int(outs[0][-1][3].max()) > 0                                  # episodes did end
+
+
+def test_a_persistent_launch_that_gave_up_is_reported_cleared_and_the_rollout_falls_back():
+    """ADVICE r4: PersistCtl::abort was set by a timed-out wait and never cleared; every later persistent launch then dropped its
+    envs after their first chunk while ranenv_rollout kept returning RANENV_OK.  Now the next rollout call sees the sticky error word
+    (host-visible), clears the queues, switches the persistent rollout off for the handle and FAILS; after a reset the handle steps
+    again -- through the launch-per-chunk rollout -- and agrees with a handle that never had the fault."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd import _lib
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    a = make_mult_slice_workload(600, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000)
+    b = make_mult_slice_workload(600, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000)
+    for wl in (a, b):
+        wl.env.set_option("compact", 1)
+    a.env.set_option("persist", 0)
+    b.env.set_option("persist", 1); b.env.set_option("persist_grid", 128); b.env.set_option("persist_chunk", 2)
+    b.env.reset(); b.env.rollout(9); torch.cuda.synchronize()
+    assert b.env.get_option("last_rollout_persistent") == 1 and b.env.get_option("persist_errors") == 0
+    b.env.set_option("persist_inject_abort", 1)
+    b.env.rollout(12)                                          # this launch finds a wait given up: envs dropped after a chunk
+    torch.cuda.synchronize()
+    steps = b.env.views()["step_number"]
+    assert int(steps.min()) < 21                               # (not every env got its 12 TTIs)
+    assert b.env.get_option("persist_errors") == 1
+    with pytest.raises(_lib.RanEnvError, match="gave up"):
+        b.env.rollout(5)
+    assert b.env.get_option("persist") == 0 and b.env.get_option("persist_errors") == 1
+    a.env.reset(); b.env.reset()
+    for k in (7, 20, 3):
+        a.env.rollout(k); b.env.rollout(k)
+        assert b.env.get_option("last_rollout_persistent") == 0
+    torch.cuda.synchronize()
+    va, vb = a.env.views(), b.env.views()
+    for k in ("queue_pkts", "pkt_effective_thr", "dropped_pkts", "rb_count", "step_number", "win_sent"):
+        assert torch.equal(va[k], vb[k]), k
+    assert torch.equal(a.env.reward, b.env.reward) and torch.equal(a.env.obs_inter, b.env.obs_inter)
+    a.env.close(); b.env.close()
