@@ -178,7 +178,7 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
                                f"an HBM pool of {args.traces}x{args.trace_len} float32 tiles{workload_extra}",
                    "batch_per_gpu": batch, "global_batch": batch * world, "n_slices": S, "n_ues": U,
                    "n_rbs": R, "parallelism": f"episodes sharded over {world} GPU(s), metrics all_gather only",
-                   "launch": schedule, "se_mode": "stream"},
+                   "launch": schedule, "se_mode": "stream", "se_layout": getattr(args, "se_layout", None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "clock": "wall clock of the timed region (same as value)",
                      "frac_algorithmic_bytes": achieved / HBM_PEAK_GBS,
@@ -255,7 +255,7 @@ def other_config_block(cfg, device, args, rank, se_pool, timing):
     st = block_stats(times, env.B * K, K)
     alg = env.algorithmic_bytes_per_env_step("stream")
     persistent, launches = env.get_option("last_rollout_persistent"), env.get_option("last_rollout_launches")
-    st.update({"workload": label, "batch": env.B, "n_slices": env.S, "n_ues": env.U, "n_rbs": env.R,
+    st.update({"workload": label, "batch": env.B, "se_layout": getattr(env, "se_layout", "rb"), "n_slices": env.S, "n_ues": env.U, "n_rbs": env.R,
                "algorithmic_bytes_per_env_step": alg,
                "roofline_frac": env.B * alg / (st["ms_per_step"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
                "launch": (f"ranenv_rollout: {launches} persistent work-queue launch(es) for the K TTIs" if persistent else
@@ -342,6 +342,8 @@ def main():
                          "~1.8 GB of env state at batch 4096: pass a smaller --traces / --trace-len if this GPU is shared.")
     env = wl.env
     batch = env.B
+    args.se_layout = ("RB-quad-major [ceil(R/4)][U][4] float32 (ranenv_bind_se_pool_quad: 16-byte loads; a copy made once at bind from the RB-major "
+                      "pool the workload generates)" if getattr(env, "se_layout", "rb") == "quad" else "RB-major [R][U] float32")
     # partitions: 3 measured best on one GPU (caller's stream + 2); a process has 4 hardware queues and RCCL wants some
     # of them in a multi-rank run, so there 2 (caller's stream + 1; within 2 % of 3 on one GPU)
     parts = args.partitions if args.partitions is not None else ((3 if world == 1 else 2) if batch >= 2048 else 1)

@@ -171,6 +171,15 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count,
 /* SE pool: float32 tiles of R*U values, RB-major (value of RB r, UE u at r*U + u), tile i at
  * dev + i*tile_stride floats; tile_stride >= U*R. */
 int ranenv_bind_se_pool(ranenv_handle h, const float *dev_pool, int64_t n_tiles, int64_t tile_stride);
+/* The same pool in RB-QUAD-MAJOR order: four consecutive RBs of a UE side by side, float32 [tile][ceil(R/4)][U][4] (value of RB r, UE u at
+ * ((r / 4) * U + u) * 4 + r % 4; zeros behind RB R-1), tile i at dev + i*tile_stride floats, tile_stride >= ceil(R/4)*U*4 and a multiple
+ * of 4, dev 16-byte aligned.  What replays pooled tiles (reset / step / step_range / step_part / rollout / step_dense without explicit
+ * tiles / the sidecar build of ranenv_set_se_mode) then loads 16 bytes per lane and instruction instead of 4: a quarter of the memory
+ * instructions, 1 KB instead of 256 B of contiguous memory per wave-load, 6.6 instead of 5.6 TB/s of stream at the headline's occupancy
+ * (DESIGN.md 4j).  Results are identical bit for bit (same values, same summation order).  Explicit per-step dev_se_tiles stay RB-major.
+ * ranenv_se_retile_quad converts an RB-major pool [n_tiles][R][U] (device pointers, no handle). */
+int ranenv_bind_se_pool_quad(ranenv_handle h, const float *dev_pool, int64_t n_tiles, int64_t tile_stride);
+int ranenv_se_retile_quad(const float *dev_rb_major, float *dev_quad, int64_t n_tiles, int32_t n_ues, int32_t n_rbs, void *stream);
 /* Traffic pool: int32 offered bits, row i = [U] at dev + i*U. */
 int ranenv_bind_traffic_pool(ranenv_handle h, const int32_t *dev_pool, int64_t n_rows);
 

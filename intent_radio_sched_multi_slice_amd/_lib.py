@@ -27,6 +27,7 @@ EXPORTS = (
     "ranenv_autoreset", "ranenv_get_poisson_tables", "ranenv_set_partitions", "ranenv_rollout", "ranenv_enable_metrics", "ranenv_get_metrics",
     "ranenv_step_range", "ranenv_set_se_mode", "ranenv_get_se_sidecars", "ranenv_step_part", "ranenv_wait_part",
     "ranenv_get_partition", "ranenv_get_part_stream", "ranenv_autoreset_part", "ranenv_set_option", "ranenv_get_option", "ranenv_profile_work", "ranenv_bind_se_gather_from_power",
+    "ranenv_bind_se_pool_quad", "ranenv_se_retile_quad",
 )
 
 
@@ -103,6 +104,8 @@ def load() -> C.CDLL:
     lib.ranenv_destroy.argtypes = [C.c_void_p]
     lib.ranenv_load_scenarios.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ScenarioTablesC), C.c_void_p]
     lib.ranenv_bind_se_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    lib.ranenv_bind_se_pool_quad.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+    lib.ranenv_se_retile_quad.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     lib.ranenv_bind_traffic_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.ranenv_set_episodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ranenv_set_policy.argtypes = [C.c_void_p, C.c_int32, C.c_int32]

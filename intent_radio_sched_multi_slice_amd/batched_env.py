@@ -150,18 +150,53 @@ class BatchedRanEnv:
         if first == 0 and tables.n_scenarios == self.n_scenarios:
             self.tables = tables
 
-    def bind_se_pool(self, se_pool: torch.Tensor):
-        """float32 [n_tiles, R, U] (RB-major tiles) resident on this GPU."""
+    def bind_se_pool(self, se_pool: torch.Tensor, layout: Optional[str] = None):
+        """float32 [n_tiles, R, U] (RB-major tiles, the order of the reference's .mat: channels/quadriga.py:70-72) resident on
+        this GPU.  ``layout``: how the library replays it -- ``"quad"`` (default; ``RANENV_SE_LAYOUT`` overrides): a copy in
+        RB-quad-major order [n_tiles, ceil(R/4), U, 4] is made once (ranenv_se_retile_quad, the same size again; the caller may
+        drop its RB-major tensor) and bound (ranenv_bind_se_pool_quad): 16-byte loads, a quarter of the memory instructions,
+        bit-identical results; ``"rb"``: the tensor itself is bound (ranenv_bind_se_pool).  A 4-D [n_tiles, ceil(R/4), U, 4]
+        tensor is taken as already re-tiled."""
         if se_pool.dtype != torch.float32 or se_pool.device != self.device or not se_pool.is_contiguous():
             raise RanEnvError("SE pool must be a contiguous float32 tensor on the env's GPU")
-        if se_pool.dim() != 3 or se_pool.shape[1] != self.R or se_pool.shape[2] != self.U:
-            raise RanEnvError(f"SE pool must be [tiles, R={self.R}, U={self.U}], got {tuple(se_pool.shape)}")
-        self._keep["se_pool"] = se_pool
-        self._check(self._lib.ranenv_bind_se_pool(self._h, _ptr(se_pool), se_pool.shape[0], self.R * self.U),
-                    "ranenv_bind_se_pool")
+        Rq = (self.R + 3) // 4
+        if se_pool.dim() == 4:
+            if tuple(se_pool.shape[1:]) != (Rq, self.U, 4):
+                raise RanEnvError(f"RB-quad-major SE pool must be [tiles, {Rq}, U={self.U}, 4], got {tuple(se_pool.shape)}")
+            quad = se_pool
+        else:
+            if se_pool.dim() != 3 or se_pool.shape[1] != self.R or se_pool.shape[2] != self.U:
+                raise RanEnvError(f"SE pool must be [tiles, R={self.R}, U={self.U}], got {tuple(se_pool.shape)}")
+            layout = layout or os.environ.get("RANENV_SE_LAYOUT") or "quad"
+            if layout not in ("quad", "rb"):
+                raise RanEnvError("layout must be 'quad' or 'rb'")
+            quad = None
+            if layout == "quad":
+                quad = torch.empty((se_pool.shape[0], Rq, self.U, 4), dtype=torch.float32, device=self.device)
+                with torch.cuda.device(self.device):
+                    st = self._lib.ranenv_se_retile_quad(_ptr(se_pool), _ptr(quad), se_pool.shape[0], self.U, self.R, self._stream())
+                if st != 0:
+                    raise RanEnvError("ranenv_se_retile_quad failed: " + (self._lib.ranenv_last_error(None) or b"").decode())
+        if quad is not None:
+            self._keep["se_pool"] = quad
+            self._check(self._lib.ranenv_bind_se_pool_quad(self._h, _ptr(quad), quad.shape[0], Rq * self.U * 4), "ranenv_bind_se_pool_quad")
+            self.se_layout = "quad"
+        else:
+            self._keep["se_pool"] = se_pool
+            self._check(self._lib.ranenv_bind_se_pool(self._h, _ptr(se_pool), se_pool.shape[0], self.R * self.U),
+                        "ranenv_bind_se_pool")
+            self.se_layout = "rb"
         self.se_mode = "stream"
         if os.environ.get("RANENV_SE_MODE") == "gather":       # experiment / test knob, like RANENV_SMALL_BATCH and RANENV_LATE
             self.set_se_mode("gather")
+
+    def pooled_tiles(self, tile_index: torch.Tensor) -> torch.Tensor:
+        """Tiles of the bound pool as float32 [n, R, U] (RB-major, the reference's order) whatever layout is bound."""
+        pool = self._keep["se_pool"]
+        t = pool.index_select(0, tile_index.to(torch.int64))
+        if t.dim() == 4:                              # RB-quad-major [n, Rq, U, 4] -> [n, 4 Rq, U] -> the first R RBs
+            t = t.permute(0, 1, 3, 2).reshape(t.shape[0], -1, self.U)[:, :self.R, :]
+        return t
 
     def set_se_mode(self, mode: str):
         """``"stream"`` (default): every TTI streams the env's whole U x R tile.  ``"gather"``: the per-UE mean over all

@@ -160,7 +160,8 @@ struct KP {
     Tables tab;
     State st;
     const ranenv_episode *episodes;
-    const float *se_pool; long long se_stride;   // RB-major pool (streaming kernels); the UE-major copy for the gather kernels
+    const float *se_pool; long long se_stride;   // RB-major or RB-quad-major pool (streaming kernels); the UE-major copy for the gather kernels
+    int se_quad;                                 // the bound pool is RB-quad-major [R/4][U][4] (ranenv_bind_se_pool_quad); explicit per-step tiles stay RB-major
     const double *se_mean_pool;                  // gather kernels: [tile][U] mean SE over the RBs of every pooled tile (sidecar)
     int se_rp;                                   // gather kernels: floats per UE row of the UE-major copy (R rounded up to 8)
     const int32_t *trf_pool;
@@ -376,21 +377,42 @@ DEVFN RowPlan make_row_plan(int n)
 #define RANENV_LATE_DEFAULT 0      /* (1 until launches ran several TTIs: their workgroups drift apart by themselves, and allocating
                                       ahead only costs its round trip through HBM -- rollout 62.1 -> 61.2, gather 37.8 -> 36.6 us per TTI) */
 #endif
+#ifndef RANENV_GATHER_CARRY
+#define RANENV_GATHER_CARRY 0      /* 1: the persistent SE gather build too carries the UE state between the TTIs of a chunk and requests the next TTI's
+                                      inputs ahead (CARRY).  Measured and left off: +15 registers = 21 spills at 5 waves per SIMD (33.3 against 31.2 us
+                                      per TTI) or 4 waves per SIMD without spills (31.7-32.3): the UE step gets slower, not faster -- that kernel is
+                                      bound by VALU issue and LDS / barrier latency at full residency, not by these round trips (profiles/r05_ab_log.txt) */
+#endif
 #ifndef RANENV_SE_DEPTH_SMALL
 #define RANENV_SE_DEPTH_SMALL 4   /* the same for batches that do not fill the CUs anyway (step kernel built for 4 waves per SIMD) */
 #endif
 
+// Two tile layouts (ranenv_bind_se_pool / ranenv_bind_se_pool_quad), a wave-uniform flag of the launch:
+//   RB-major       [R][U]        one dword per RB and lane: 8 load instructions per group of 8 RBs
+//   RB-quad-major  [R/4][U][4]   four consecutive RBs of a UE side by side: one dwordx4 per four RBs, 2 instructions per group.  A wave-load
+//                                then covers 1 KB of contiguous memory instead of 256 B and a tile takes a quarter of the memory
+//                                instructions: the same registers in flight stream 6.6 instead of 5.6 TB/s at the headline's
+//                                occupancy (tools/tile_probe.hip, profiles/r05_ab_log.txt), and a whole row of 135 RBs is 34
+//                                instructions per lane -- below the 63 a wave can have in flight (vmcnt is a 6-bit counter).
+typedef float se_v4f __attribute__((ext_vector_type(4)));
 template <int SE_NQ>              // 8-row groups in flight per lane
 struct SeStream {
     float q[SE_NQ][8];
     __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform descriptor of the tile (SGPRs)
-    int voff, row_bytes;
-
-    int last_row;                  // byte offset of the tile's last row
-    DEVFN void load(float (&dst)[8], int r0)
+    int voff, row_bytes;           // lane's byte offset inside a (quad-)row; bytes per (quad-)row
+    bool quad;
+    int last_row;                  // byte offset of the tile's last (quad-)row
+    DEVFN void load(float (&dst)[8], int r0)            // r0: a multiple of 8
     {
         // The scalar offset of a buffer load takes no part in the descriptor's range check: rows past the tile (the
         // padding of the last, partial group, never summed) are clamped to the last row instead (scalar min).
+        if (quad) {
+            const int s0 = (r0 >> 2) * row_bytes, s1 = s0 + row_bytes;
+            const se_v4f a = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 < last_row ? s0 : last_row, 0));
+            const se_v4f b = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s1 < last_row ? s1 : last_row, 0));
+            dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+            return;
+        }
         int soff = r0 * row_bytes;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -399,10 +421,12 @@ struct SeStream {
             soff += row_bytes;
         }
     }
-    DEVFN void init(const float *tile, int U, int u, int R)
+    DEVFN void init(const float *tile, int U, int u, int R, bool quad_ = false)
     {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, U * R * 4, 0x00020000);
-        voff = u * 4; row_bytes = U * 4; last_row = (R - 1) * U * 4;
+        quad = quad_;
+        const int rows = quad ? (R + 3) >> 2 : R, rbytes = quad ? U * 16 : U * 4;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, rows * rbytes, 0x00020000);
+        voff = quad ? u * 16 : u * 4; row_bytes = rbytes; last_row = (rows - 1) * rbytes;
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
@@ -423,17 +447,25 @@ struct SeStream {
 template <int SE_NQ>
 struct SeStreamLane {
     float q[SE_NQ][8];
-    const float *col;              // tile + u
+    const float *col;              // tile + u (RB-major) / tile + 4 u (RB-quad-major)
     int U, R;
+    bool quad;
     static constexpr int NSLOT = SE_NQ;
     DEVFN void load(float (&dst)[8], int r0)
     {
+        if (quad) {
+            const int nq = (R + 3) >> 2, q0 = r0 >> 2, q1 = q0 + 1 < nq ? q0 + 1 : nq - 1;
+            const se_v4f a = *(const se_v4f *)(col + (size_t)q0 * U * 4), b = *(const se_v4f *)(col + (size_t)q1 * U * 4);
+            dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) { const int r = r0 + j < R ? r0 + j : R - 1; dst[j] = col[(size_t)r * U]; }
     }
-    DEVFN void init(const float *tile, int U_, int u, int R_)
+    DEVFN void init(const float *tile, int U_, int u, int R_, bool quad_ = false)
     {
-        col = tile + u; U = U_; R = R_;
+        quad = quad_;
+        col = tile + (quad ? 4 * u : u); U = U_; R = R_;
 #pragma unroll
         for (int d = 0; d < SE_NQ; d++) if (d * 8 < R) load(q[d], d * 8);
     }
@@ -659,6 +691,13 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
                           kernel, dumped into policy_scores[e][k] instead of the scores (tools/stamps.py) */
 #define RANENV_STAMP(k) do { if (!PERSIST && threadIdx.x == 0 && (k) < p.S) \
     ST_policy_scores(p)[(size_t)(p.e0 + blockIdx.x) * p.S + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#elif RANENV_DIAG == 12 /* diagnostic build for the PERSISTENT launches (tools/persist_phases.py): thread 0 adds the time since its previous
+                          stamp to policy_scores[e][k] (fire-and-forget atomics): [1..8] the phases of a TTI, [0] the gap between two TTIs of
+                          a chunk, [9] TTIs counted; the scores themselves are not written.  Needs S >= 10. */
+#define RANENV_STAMP(k) do { if constexpr (PERSIST) if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    double *d_ = &ST_policy_scores(p)[(size_t)e * p.S]; \
+    if ((k) == 0) { if (warm) acc_add(d_, (double)(now_ - cy.last_stamp)); acc_add(d_ + 9, 1.0); } else acc_add(d_ + (k), (double)(now_ - stamp_prev)); \
+    stamp_prev = now_; if ((k) == 8) cy.last_stamp = now_; } } while (0)
 #else
 #define RANENV_STAMP(k) do { } while (0)
 #endif
@@ -822,7 +861,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
         } else if (ok1) {
             score = p.scores ? row_at<PACK>(p.scores, (size_t)e * S * 8, (unsigned)s1 * 8u) : (nues1 > 0 ? 1.0 : -1.0);   // marr.py:40-47
         }
-#if RANENV_DIAG != 9
+#if RANENV_DIAG != 9 && RANENV_DIAG != 12
         if (ok1) row_at<PACK>(scores_out, (size_t)e * S * 8, (unsigned)s1 * 8u) = score;
 #endif
         if (tid < GRP) xs[3][s1] = score;
@@ -979,6 +1018,15 @@ struct StepCarry {
     int u, slc, ue_pos, pkt_size, max_pkts, max_age, total;
     long long win_sent;
     double sem_prev;
+    // CARRY builds (see step_body): the rest of the UE's state, and what the next TTI would otherwise load at its entry or in the
+    // middle of its UE step -- requested a TTI ahead: the window slots it gives up, its traffic word, the two age-list entries behind the head
+    long long sum_age, win_drop;
+    int front, front_rem, fifo;
+    int pf_old_s, pf_old_d, pf_traffic;
+    int2 pf1, pf2;
+#if RANENV_DIAG == 12
+    unsigned long long last_stamp;
+#endif
 };
 
 template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, int PACK = 1, bool MIX = false, typename P>
@@ -993,6 +1041,15 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     static_assert(PACK == 1 || (PACK == 2 && MODE == MODE_STEP && !PERSIST), "packed waves: step launches only");
     constexpr int LW = WAVE / PACK;                  // lanes per env
     constexpr int GDEPTH = (GATHER && NQ == 0) ? 1 : 2;      // gather builds: NQ = 0 asks for one 8-RB group in flight instead of two
+    // CARRY (persistent builds with registers to spare): a TTI that follows another TTI of the same env in the same chunk loads
+    // NOTHING of the UE's state -- the previous TTI hands all of it over in registers (StepCarry) and has requested, behind its own
+    // stores, what only the next TTI's position determines: the two window slots that push will give up, its traffic word, and
+    // the two age-list entries behind the head (the UE step pops ~1 entry per TTI; each pop used to be a dependent load in the
+    // middle of the step).  A workgroup's TTI is a chain of dependent round trips (1-2 us each under load); this removes the state
+    // round trip and the age-list ones.  For the whole-row streaming build it also frees the way for the tile: memory operations
+    // retire in issue order, so the burst of the next TTI's tile may only follow the TTI's last dependent load -- with the UE step
+    // loading nothing the burst moves from behind the UE step to right behind the stream phase.
+    constexpr bool CARRY = PERSIST && MODE == MODE_STEP && PACK == 1 && ((!GATHER && NQ >= 8) || (GATHER && RANENV_GATHER_CARRY != 0));
     // MIX (ranenv_core_kernel_mixed): a two-wave block steps either one env of more than 64 slice members with both waves, or --
     // `narrow` -- two envs of at most 64, one per wave, each wave a workgroup of its own: its own LDS image, lanes counted from its
     // own first lane, no block barrier (wg_sync(narrow))
@@ -1020,6 +1077,9 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
         return (long long)(((unsigned long long)hi32 << 32) | lo32);
     };
+#if RANENV_DIAG == 12
+    unsigned long long stamp_prev = 0;
+#endif
     RANENV_STAMP(0);
 #if RANENV_COLD_ARGS
     // The kernel's argument block, read in place: a field that only a late role needs is fetched there (one scalar load)
@@ -1116,7 +1176,14 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     int old_s = 0, old_d = 0;
     double traffic = 0.0;
     const bool gen_traffic = MODE != MODE_RESET && p.traffic_bits == nullptr && p.trf_gen != 0;
+    const bool carried = CARRY && warm;
     auto rest_of_state = [&]() {
+        if (carried) {           // (this lane pushed at the previous TTI: lastp == ptot already)
+            sum_age = cy.sum_age; front = cy.front; front_rem = cy.front_rem; fifo = cy.fifo; win_drop = cy.win_drop;
+            old_s = cy.pf_old_s; old_d = cy.pf_old_d;
+            if (!gen_traffic) traffic = (double)cy.pf_traffic;
+            return;
+        }
         if (MODE != MODE_RESET) {
             sum_age = UE8(queue_age_sum);
             front = UE4(front); front_rem = UE4(front_rem); fifo = UE4(fifo);
@@ -1154,7 +1221,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 #endif
     if (pre) {
         rb_start = UE4(next_rb_start); rb_count = UE4(next_rb_count);
-#if RANENV_DIAG != 9
+#if RANENV_DIAG != 9 && RANENV_DIAG != 12
         if (tid < S) row_at<PACK>(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at<PACK>(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
 #endif
     }
@@ -1168,7 +1235,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     typedef std::conditional_t<PACK == 2, SeStreamLane<GATHER ? 1 : NQ>, SeStream<GATHER ? 1 : NQ>> SeQ;
     SeQ se_local;
     SeQ &se1 = SE_AHEAD ? *se_carry : se_local;
-    if (!GATHER && !(SE_AHEAD && se_ready)) se1.init(tile, U, u, R);          // lane = UE: one dword per RB
+    const bool se_quad = !GATHER && p.se_quad != 0 && p.se_tiles == nullptr;   // (explicit per-step tiles are RB-major)
+    if (!GATHER && !(SE_AHEAD && se_ready)) se1.init(tile, U, u, R, se_quad);          // lane = UE
     asm volatile("" ::: "memory");
     // wave 0 zeroes what can be read of the per-slice rows (NP positions of S slices: nothing reads further) and parks the tables.
     // A warm TTI finds both as it needs them: the tables are the scenario's, and every role writes a slice's rows at its
@@ -1194,6 +1262,21 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         alloc_front<NP, PACK>(p, sh, tid, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
                     rb_start, rb_count, ST_policy_scores(p), narrow);
     RANENV_STAMP(2);
+
+    // MultSliceTraffic.step (traffics/mult_slice.py:24-32) drawn instead of replayed: Poisson(slice Mbps) * 1e6 bits for the UEs of a
+    // slice that has a request, 0 elsewhere.  A function of (env, episode, TTI, UE) alone.
+    auto draw_traffic = [&]() -> double {
+        if (!(slc >= 0 && sh.si[slc][1] != 0 && sh.sf[slc][1] > 0.0)) return 0.0;
+        unsigned rnd[4];
+        philox4x32_10((unsigned)(COLD(env_id_base) + e), (unsigned)episode_no, (unsigned)t, (unsigned)u,
+                      (unsigned)COLD(trf_seed), (unsigned)(COLD(trf_seed) >> 32), rnd);
+        const size_t row = (size_t)sc * S + slc;
+        const int k = poisson_draw(COLD(pois_cdf) + row * 256, COLD(pois_guide) + row * 64, ((unsigned long long)rnd[1] << 32) | rnd[0]);
+        return (double)k * 1e6;
+    };
+    // (CARRY builds: drawn here, ahead of the stream, so that the UE step behind it makes no dependent load -- the table look-ups
+    // retire behind the tile, which the stream phase waits for anyway)
+    if (CARRY && gen_traffic && act) traffic = draw_traffic();
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
     double my_full = 0.0, my_part = 0.0;
@@ -1223,6 +1306,17 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     if constexpr (DEFER == 2) {
         if (!(GATHER && RANENV_GATHER_STATE_FIRST))
             rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
+    }
+    if constexpr (SE_AHEAD && CARRY) {
+        // The next TTI's tile of this env (the position it will derive itself: cy.se_pos below), requested as soon as the queue's
+        // registers are free: in a carried TTI nothing the UE step needs is loaded behind it (in the first TTI of a chunk the UE step's
+        // age-list loads queue behind the burst: once per chunk).
+        if (se_next) {
+            const int pos_next = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
+            asm volatile("" ::: "memory");
+            se1.init(p.se_pool + (size_t)(ep.se_base + (long long)pos_next) * (size_t)p.se_stride, U, u, R, se_quad);
+            asm volatile("" ::: "memory");
+        }
     }
     RANENV_STAMP(3);
     wg_sync(narrow);        // every thread is done with the allocation's use of the per-slice rows
@@ -1254,23 +1348,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         }
         const double se_mean_new = GATHER ? sem_tile : my_full / (double)R, se_part = my_part;
         int dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;     // all < 2^31 (host validates the packet counts)
+        int adm_now = 0;                                        // packets admitted at this TTI (its age-list entry, if any)
         if (MODE != MODE_RESET) {
             const double psz = (double)pkt_size;
             // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
-            if (gen_traffic) {
-                // MultSliceTraffic.step (traffics/mult_slice.py:24-32): Poisson(slice Mbps) * 1e6 bits for the UEs of a
-                // slice that has a request, 0 elsewhere; drawn here instead of replayed
-                traffic = 0.0;
-                if (slc >= 0 && sh.si[slc][1] != 0 && sh.sf[slc][1] > 0.0) {
-                    unsigned rnd[4];
-                    philox4x32_10((unsigned)(COLD(env_id_base) + e), (unsigned)episode_no, (unsigned)t, (unsigned)u,
-                                  (unsigned)COLD(trf_seed), (unsigned)(COLD(trf_seed) >> 32), rnd);
-                    const size_t row = (size_t)sc * S + slc;
-                    const int k = poisson_draw(COLD(pois_cdf) + row * 256, COLD(pois_guide) + row * 64,
-                                               ((unsigned long long)rnd[1] << 32) | rnd[0]);
-                    traffic = (double)k * 1e6;
-                }
-            }
+            if (gen_traffic && !CARRY) traffic = draw_traffic();
             pkt_thr = (int)((se_part * COLD(bw_per_rb)) / psz);
             pkt_in = (int)(traffic / psz);
             const int L = p.L;
@@ -1281,7 +1363,15 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             int2 *ring_env = ST_age_ring(p) + (size_t)e * L * U;        // (uniform; entry k of this UE at [k * U + u])
             int head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
             auto pop_head = [&]() { nent--; head = head + 1 == L ? 0 : head + 1; };
-            auto load_head = [&]() { const int2 en = row_at<PACK>(ring_env, 0, (unsigned)(head * U + u) * 8u); front = en.x; front_rem = en.y; };
+            // the k-th pop of a TTI that leaves an older entry at the head needs entry k behind the head the TTI started with: the
+            // first two were requested at the end of the previous TTI (carried), only a UE that pops more loads here
+            int loads = 0;
+            const int pf1x = cy.pf1.x, pf1y = cy.pf1.y, pf2x = cy.pf2.x, pf2y = cy.pf2.y;      // (by value: StepCarry must stay in registers)
+            auto load_head = [&]() {
+                loads++;
+                if (carried && loads <= 2) { front = loads == 1 ? pf1x : pf2x; front_rem = loads == 1 ? pf1y : pf2y; }
+                else { const int2 en = row_at<PACK>(ring_env, 0, (unsigned)(head * U + u) * 8u); front = en.x; front_rem = en.y; }
+            };
             if (nent > 0 && front == t - max_age - 1) {         // receive: the bin older than max_age expires
                 dropped += front_rem; total -= front_rem; sum_age -= (long long)max_age * front_rem;
                 front_rem = 0;
@@ -1313,6 +1403,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
                 }
             }
             fifo = head | (nent << 16);
+            adm_now = adm;
         }
         // A UE that was not stepped for a while (outside every slice, compact mode) missed the pushes [lastp, ptot): each
         // would have pushed zeros.  Made up for here, oldest first; only the last D matter.  A push at index q finds the
@@ -1352,6 +1443,35 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 
         UE8(se_mean) = se_mean_new; sem_new = se_mean_new;
         UE4(rb_start) = rb_start; UE4(rb_count) = rb_count;
+        if constexpr (CARRY) {
+            // Hand-over to the next TTI of this chunk (if there is one): the state in registers, and -- requested here, behind this
+            // TTI's stores (catch-up and push included: a load behind a store of the same lane sees it) -- what its position determines.
+            cy.sum_age = sum_age; cy.win_drop = win_drop; cy.front = front; cy.front_rem = front_rem; cy.fifo = fifo;
+            int ps = 0, pd = 0, pt = 0;
+            int2 e1 = make_int2(0, 0), e2 = make_int2(0, 0);
+            if (se_next) {
+                const int np1 = npush + 1 == D ? 0 : npush + 1;
+                if (hlen_new == D) {                            // the next push finds the window full: it gives up what slot np1 holds
+                    if (D == 1) { ps = sent; pd = dropped; }    // (a one-deep window: the slot this TTI has just written)
+                    else {
+                        ps = row_at<PACK>(ST_ring_sent(p), ((size_t)e * D + np1) * U * 4, u4);
+                        pd = row_at<PACK>(ST_ring_drop(p), ((size_t)e * D + np1) * U * 4, u4);
+                    }
+                }
+                if (!gen_traffic) {
+                    const int tp1 = trf_pos + 1 >= ep.trf_len ? 0 : trf_pos + 1;
+                    pt = row_at<PACK>(p.trf_pool, ((size_t)ep.trf_base + (size_t)tp1) * U * 4, u4);
+                }
+                const int L = p.L, head = fifo & 0xffff, nent = (int)((unsigned)fifo >> 16);
+                const int h1 = head + 1 >= L ? head + 1 - L : head + 1, h2 = head + 2 >= L ? head + 2 - L : head + 2;
+                int2 *ring_env = ST_age_ring(p) + (size_t)e * L * U;
+                // (this TTI's own entry is the list's last and untouched unless it is the head: taken from registers, not loaded back)
+                const bool own1 = adm_now > 0 && nent == 2, own2 = adm_now > 0 && nent == 3;
+                if (own1) e1 = make_int2(t, adm_now); else if (nent > 1) e1 = row_at<PACK>(ring_env, 0, (unsigned)(h1 * U + u) * 8u);
+                if (own2) e2 = make_int2(t, adm_now); else if (nent > 2) e2 = row_at<PACK>(ring_env, 0, (unsigned)(h2 * U + u) * 8u);
+            }
+            cy.pf_old_s = ps; cy.pf_old_d = pd; cy.pf_traffic = pt; cy.pf1 = e1; cy.pf2 = e2;
+        }
         const double occ_new = (double)total / (double)max_pkts;
         const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
@@ -1438,11 +1558,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if ((tid & (LW - 1)) == 0) { acc_add(COLD(acc) + (size_t)e * 8 + 6, ws); acc_add(COLD(acc) + (size_t)e * 8 + 7, wd); }
     }
     RANENV_STAMP(5);
-    if constexpr (SE_AHEAD) {
+    if constexpr (SE_AHEAD && !CARRY) {
         if (se_next) {         // the next TTI's tile of this env (the position it will derive itself: cy.se_pos below)
             const int pos_next = se_pos + 1 >= ep.se_len ? 0 : se_pos + 1;
             asm volatile("" ::: "memory");           // (behind this TTI's state stores in program order: they need no register)
-            se1.init(p.se_pool + (size_t)(ep.se_base + (long long)pos_next) * (size_t)p.se_stride, U, u, R);
+            se1.init(p.se_pool + (size_t)(ep.se_base + (long long)pos_next) * (size_t)p.se_stride, U, u, R, se_quad);
             asm volatile("" ::: "memory");
         }
     }
@@ -1895,7 +2015,10 @@ DEVFN void persist_loop()
             for (int k = 0; k < n; k++) {
                 kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
                 asm volatile("" : "+s"(kc));
-                const bool ahead = RANENV_WARM_ENTRY != 0 && k + 1 < n;       // the next TTI of this chunk enters warm
+                // another TTI of this env follows in this launch and enters warm if this workgroup makes it: the next one of the chunk, or
+                // -- the workgroup keeps its env at most chunk ends -- the next chunk's first (what is requested ahead for it is wasted
+                // when the env changes hands)
+                const bool ahead = RANENV_WARM_ENTRY != 0 && done + k + 1 < n_tti;
                 (void)step_body<MODE_STEP, NQ, GATHER, NP, true>(*kc, cy, warm, e, &seq, se_ready, ahead);
                 se_ready = ahead;
                 if (k + 1 < n) { warm = RANENV_WARM_ENTRY != 0; if (warm) wg_sync(); else full_sync(); }
@@ -1919,11 +2042,15 @@ DEVFN void persist_loop()
 #ifndef RANENV_PERSIST_WAVES_PER_EU
 #define RANENV_PERSIST_WAVES_PER_EU 5
 #endif
+#ifndef RANENV_PERSIST_GATHER_WAVES
+#define RANENV_PERSIST_GATHER_WAVES 5
+#endif
+#define RANENV_PERSIST_WPE ((NP == 16) ? 4 : (GATHER ? RANENV_PERSIST_GATHER_WAVES : RANENV_PERSIST_WAVES_PER_EU))
 template <bool GATHER, int NP>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(NP == 16 ? 4 : RANENV_PERSIST_WAVES_PER_EU, NP == 16 ? 4 : RANENV_PERSIST_WAVES_PER_EU))) ranenv_persist_kernel(const KP p)
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_PERSIST_WPE, RANENV_PERSIST_WPE))) ranenv_persist_kernel(const KP p)
 {
     (void)p;                                         // (read in place, like step_loop)
-#if RANENV_DIAG == 0                                 /* (the diagnostic / ablation builds run the launch-per-chunk rollout only) */
+#if RANENV_DIAG == 0 || RANENV_DIAG == 12            /* (the other diagnostic / ablation builds run the launch-per-chunk rollout only) */
     persist_loop<GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP>();
 #endif
 }
@@ -1932,13 +2059,13 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(NP
 // taking, so a lane keeps its whole SE row in flight (16 groups of 8 loads): the stream phase of a workgroup's chain is one
 // memory latency instead of four (profiles/r04_ab_log.txt: 23.4 against 26.6 us per TTI).  Streaming only.
 #ifndef RANENV_SE_DEPTH_TINY
-#define RANENV_SE_DEPTH_TINY 16
+#define RANENV_SE_DEPTH_TINY 17       /* R = 135: 16 groups of 8 + the tail group -- the whole row, no load is requested inside the stream phase */
 #endif
 template <int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ranenv_persist_kernel_tiny(const KP p)
 {
     (void)p;
-#if RANENV_DIAG == 0
+#if RANENV_DIAG == 0 || RANENV_DIAG == 12
     persist_loop<RANENV_SE_DEPTH_TINY, false, NP>();
 #endif
 }
@@ -2037,21 +2164,38 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)
 // One workgroup per tile, thread = UE for the means; the copy is a plain index transform (reads served by L2).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CORE_NT) ranenv_se_sidecar_kernel(const float *pool, long long stride, long long tile0, int U, int R, int Rp,
-                                                                    double *mean, float *um)
+                                                                    int quad, double *mean, float *um)
 {
     const long long t = tile0 + blockIdx.x;
     const float *tile = pool + (size_t)t * (size_t)stride;
     const int tid = threadIdx.x;
     const int u = tid < U ? tid : U - 1;
     SeStream<4> se;
-    se.init(tile, U, u, R);
+    se.init(tile, U, u, R, quad != 0);
     double full = 0.0, part = 0.0;
     row_sums(se, R, [](int) { return false; }, full, part, []() {});
     if (tid < U) mean[(size_t)t * U + tid] = full / (double)R;
     float *out = um + (size_t)t * (size_t)U * Rp;
     for (int i = tid; i < U * Rp; i += (int)blockDim.x) {
         const int uu = i / Rp, r = i - uu * Rp;
-        out[i] = r < R ? tile[(size_t)r * U + uu] : 0.0f;
+        out[i] = r < R ? (quad ? tile[((size_t)(r >> 2) * U + uu) * 4 + (r & 3)] : tile[(size_t)r * U + uu]) : 0.0f;
+    }
+}
+
+// RB-major [n][R][U] -> RB-quad-major [n][ceil(R/4)][U][4] (ranenv_se_retile_quad): one float4 of the output per thread, zeros behind RB R-1
+__global__ void __launch_bounds__(256) ranenv_se_retile_quad_kernel(const float *src, float *dst, long long n_quads, int U, int R)
+{
+    const int Rq = (R + 3) >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = i / ((long long)Rq * U);
+        const int rem = (int)(i - t * (long long)Rq * U), qr = rem / U, u = rem - qr * U;
+        const float *tile = src + (size_t)t * (size_t)U * R;
+        se_v4f v;
+        v.x = tile[(size_t)(4 * qr) * U + u];
+        v.y = 4 * qr + 1 < R ? tile[(size_t)(4 * qr + 1) * U + u] : 0.0f;
+        v.z = 4 * qr + 2 < R ? tile[(size_t)(4 * qr + 2) * U + u] : 0.0f;
+        v.w = 4 * qr + 3 < R ? tile[(size_t)(4 * qr + 3) * U + u] : 0.0f;
+        ((se_v4f *)dst)[i] = v;
     }
 }
 
@@ -3320,13 +3464,43 @@ int ranenv_bind_se_pool(ranenv_handle h, const float *dev_pool, int64_t n_tiles,
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     h->se_mode = RANENV_SE_STREAM;             // the sidecars describe the pool they were built from
     if (dev_pool == nullptr) {
-        h->kp.se_pool = nullptr; h->kp.se_stride = 0; h->se_tiles_n = 0;
+        h->kp.se_pool = nullptr; h->kp.se_stride = 0; h->se_tiles_n = 0; h->kp.se_quad = 0;
         return RANENV_OK;
     }
     if (n_tiles < 1 || tile_stride < (int64_t)h->cfg.n_ues * h->cfg.n_rbs)
         return fail(h, RANENV_E_INVALID, "SE pool needs n_tiles >= 1 and tile_stride >= U*R");
-    h->kp.se_pool = dev_pool; h->kp.se_stride = tile_stride; h->se_tiles_n = n_tiles;
+    h->kp.se_pool = dev_pool; h->kp.se_stride = tile_stride; h->se_tiles_n = n_tiles; h->kp.se_quad = 0;
     h->have_episodes = false;  // descriptors are re-validated against the new pool
+    return RANENV_OK;
+}
+
+int ranenv_bind_se_pool_quad(ranenv_handle h, const float *dev_pool, int64_t n_tiles, int64_t tile_stride)
+{
+    if (!h) return fail(h, RANENV_E_INVALID, "null handle");
+    const int64_t need = (int64_t)((h->cfg.n_rbs + 3) / 4) * h->cfg.n_ues * 4;
+    if (dev_pool == nullptr) return ranenv_bind_se_pool(h, nullptr, 0, 0);
+    if (n_tiles < 1 || tile_stride < need || (tile_stride & 3) != 0 || ((uintptr_t)dev_pool & 15) != 0)
+        return fail(h, RANENV_E_INVALID, "RB-quad-major SE pool needs n_tiles >= 1, tile_stride >= ceil(R/4)*U*4 = %lld floats and a multiple of 4, "
+                    "and a 16-byte aligned pool", (long long)need);
+    h->se_mode = RANENV_SE_STREAM;
+    h->kp.se_pool = dev_pool; h->kp.se_stride = tile_stride; h->se_tiles_n = n_tiles; h->kp.se_quad = 1;
+    h->have_episodes = false;
+    return RANENV_OK;
+}
+
+int ranenv_se_retile_quad(const float *dev_rb_major, float *dev_quad, int64_t n_tiles, int32_t n_ues, int32_t n_rbs, void *stream)
+{
+    if (!dev_rb_major || !dev_quad) return fail(nullptr, RANENV_E_INVALID, "null argument");
+    if (n_tiles < 0 || n_ues < 1 || n_rbs < 1) return fail(nullptr, RANENV_E_INVALID, "bad sizes");
+    if (((uintptr_t)dev_quad & 15) != 0) return fail(nullptr, RANENV_E_INVALID, "the RB-quad-major pool must be 16-byte aligned");
+    const long long n_quads = (long long)n_tiles * ((n_rbs + 3) / 4) * n_ues;
+    if (n_quads == 0) return RANENV_OK;
+    long long blocks = (n_quads + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(ranenv_se_retile_quad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dev_rb_major, dev_quad, n_quads,
+                       (int)n_ues, (int)n_rbs);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, RANENV_E_HIP, "se_retile_quad launch: %s", hipGetErrorString(e));
     return RANENV_OK;
 }
 
@@ -3541,7 +3715,7 @@ int ranenv_set_se_mode(ranenv_handle h, int32_t mode, void *stream_)
     for (size_t t0 = 0; t0 < nt; t0 += 1u << 20) {              // grid.x stays far below its limit
         const size_t n = nt - t0 < (1u << 20) ? nt - t0 : (1u << 20);
         hipLaunchKernelGGL(ranenv_se_sidecar_kernel, dim3((unsigned)n), dim3((unsigned)h->nt), 0, stream, h->kp.se_pool,
-                           (long long)h->kp.se_stride, (long long)t0, U, R, Rp, h->d_se_mean, h->d_se_um);
+                           (long long)h->kp.se_stride, (long long)t0, U, R, Rp, h->kp.se_quad, h->d_se_mean, h->d_se_um);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "SE sidecar launch: %s", hipGetErrorString(e));
@@ -3709,7 +3883,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    const bool persist_wanted = RANENV_DIAG == 0 && (h->persist == 1 || (h->persist < 0 && ((h->se_mode == RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))));
+    const bool persist_wanted = (RANENV_DIAG == 0 || RANENV_DIAG == 12) && (h->persist == 1 || (h->persist < 0 && ((h->se_mode == RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))));
     // (auto: where it was measured to win or tie -- profiles/r04_ab_log.txt.  Gather mode: B 1024 -4...-6 %, 2048 -1 %, 4096 -6 %, 8192 -2 % per
     // TTI; a batch of several times what the chip holds -- 16 384 one-wave envs at the reference's own size -- swaps at every chunk and
     // loses 7 %.  Streaming: -10 % at <= 2 waves per SIMD with the whole-row build; at B 4096 a tie: six same-box pairs against the

@@ -141,7 +141,7 @@ class HistoryRecorder:
         else:
             d = self._desc
             tile = d["se_base"] + (d["se_offset"] + self.t) % d["se_len"]
-            self.buf["se"][tt, cols] = env._keep["se_pool"].index_select(0, torch.as_tensor(tile, device=env.device))
+            self.buf["se"][tt, cols] = env.pooled_tiles(torch.as_tensor(tile, device=env.device))
         self.t += 1
         d = done.index_select(0, i).cpu().numpy().astype(bool)         # recording is a diagnostic mode: one small sync
         if d.any():

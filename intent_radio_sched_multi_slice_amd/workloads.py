@@ -101,7 +101,8 @@ def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POL
                              n_slices: int = 10, n_ues: int = 100, n_rbs: int = 135, rbs_per_rbg: int = 1,
                              max_ues_slice: int = 10, max_steps: int = 1000, rank: int = 0,
                              name: Optional[str] = None, flags: int = 0, min_slices: Optional[int] = None,
-                             min_ues: Optional[int] = None, se_pool: Optional[torch.Tensor] = None) -> Workload:
+                             min_ues: Optional[int] = None, se_pool: Optional[torch.Tensor] = None,
+                             se_layout: Optional[str] = None) -> Workload:
     """BASELINE configs 2-4: S 10 / U 100 / R 135 allocation units, 6..10 active slices with
     distinct templates, 4..10 UEs per slice, MimicQuadriga-law SE replayed from HBM."""
     tables = generate_scaled_scenarios(n_scenarios, seed=seed, n_slices=n_slices, n_ues=n_ues,
@@ -114,7 +115,7 @@ def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POL
     env.load_scenarios(tables)
     se_pool = _se_pool_or(se_pool, n_traces, trace_len, n_ues, n_rbs, seed + 1000 * (rank + 1), env.device)
     trf = torch.from_numpy(poisson_traffic_pool(tables, trace_len, seed + 7)).to(env.device)
-    env.bind_se_pool(se_pool)
+    env.bind_se_pool(se_pool, layout=se_layout)
     env.bind_traffic_pool(trf)
     rng = np.random.default_rng(seed + 31 * (rank + 1))
     scenario = rng.integers(0, n_scenarios, batch)
@@ -132,7 +133,7 @@ def make_mult_slice_seq_workload(batch: int, device: torch.device, policy: int =
                                  trace_len: int = 200, seed: int = 10, n_slices: int = 10, n_ues: int = 100,
                                  n_rbs: int = 135, rbs_per_rbg: int = 1, max_ues_slice: int = 10,
                                  max_steps: int = 1000, rank: int = 0, flags: int = 0,
-                                 se_pool: Optional[torch.Tensor] = None) -> Workload:
+                                 se_pool: Optional[torch.Tensor] = None, se_layout: Optional[str] = None) -> Workload:
     """BASELINE configs[4]: the ``mult_slice_seq`` per-scenario sweep.  Env e plays episode number
     ``rank*batch + e``; like MultSliceAssociationSeq / QuadrigaChannelSeq (associations/mult_slice_seq.py:38-46,
     channels/quadriga_seq.py:28-39) the association scenario is ``episode // channels_per_scenario`` (mod
@@ -148,7 +149,7 @@ def make_mult_slice_seq_workload(batch: int, device: torch.device, policy: int =
     env.load_scenarios(tables)
     se_pool = _se_pool_or(se_pool, n_traces, trace_len, n_ues, n_rbs, seed + 1000 * (rank + 1), env.device)
     trf = torch.from_numpy(poisson_traffic_pool(tables, trace_len, seed + 7)).to(env.device)
-    env.bind_se_pool(se_pool)
+    env.bind_se_pool(se_pool, layout=se_layout)
     env.bind_traffic_pool(trf)
     episode = np.arange(batch, dtype=np.int64) + rank * batch
     scenario = (episode // channels_per_scenario) % n_groups

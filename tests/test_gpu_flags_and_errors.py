@@ -537,8 +537,9 @@ def test_a_persistent_launch_that_gave_up_is_reported_cleared_and_the_rollout_fa
     from intent_radio_sched_multi_slice_amd import _lib
     from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
     dev = torch.device("cuda", 0)
-    a = make_mult_slice_workload(600, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000)
-    b = make_mult_slice_workload(600, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000)
+    # (a clearing reset: the 10-TTI window does not carry b's broken rollout into the comparison)
+    a = make_mult_slice_workload(600, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000, flags=_lib.F_CLEAR_HISTORY_ON_RESET)
+    b = make_mult_slice_workload(600, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000, flags=_lib.F_CLEAR_HISTORY_ON_RESET)
     for wl in (a, b):
         wl.env.set_option("compact", 1)
     a.env.set_option("persist", 0)
