@@ -47,7 +47,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ, VALU_CYCLES = 256 * 4, 2.4e9, 4.0   # 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction issues over >= 4 cycles
-PMC_FILE = os.path.join("profiles", "r04_pmc.json")   # rocprofv3 --pmc passes of the schedule timed here (tools/profile_rollout.py, pmc_collect_r4.py)
+PMC_FILE = os.path.join("profiles", "r05_pmc.json")   # rocprofv3 --pmc passes of the schedule timed here (tools/profile_rollout.py, pmc_collect_r4.py, round5_measure.sh)
 REFPY_FILE = os.path.join("profiles", "r04_reference_python.json")   # the reference's own Python, timed in the build container
 SAMPLE_S = 0.020                                      # stepping time sampled per timed variant
 
