@@ -2708,6 +2708,7 @@ void launch_kernels(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStr
 
 int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts);
 bool persist_tiny(ranenv_handle h);
+bool stream_capturing(hipStream_t stream);
 
 // Packed waves address a per-env row as (uniform array base) + (32-bit row + lane offset), see row_at<2>: every array they
 // address that way must stay below 4 GB.  True for every size a packed step makes sense at (the reference's: megabytes); a handle
@@ -2822,6 +2823,7 @@ int compact_for(ranenv_handle h, const KP &kp, hipStream_t stream, int *out)
     if (kp.trf_gen) { *out = (h->compact_enabled && h->idle_state_clean) ? 1 : 0; return RANENV_OK; }
     if (!kp.trf_pool) return RANENV_OK;
     if (!h->compact_enabled) return RANENV_OK;
+    if (h->idle_check_dirty && stream_capturing(stream)) return RANENV_OK;     // (the examination reads back: a captured step that comes before it runs at full width)
     if (h->idle_check_dirty) {
         if (!h->d_violations && dev_alloc(h, &h->d_violations, 2) != RANENV_OK) return RANENV_E_NOMEM;
         HIP_TRY(h, hipMemsetAsync(h->d_violations, 0, 2 * sizeof(int), stream));

@@ -565,3 +565,31 @@ def test_a_persistent_launch_that_gave_up_is_reported_cleared_and_the_rollout_fa
         assert torch.equal(va[k], vb[k]), k
     assert torch.equal(a.env.reward, b.env.reward) and torch.equal(a.env.obs_inter, b.env.obs_inter)
     a.env.close(); b.env.close()
+
+
+def test_the_very_first_step_of_a_handle_can_be_captured():
+    """The examination of the traffic pool for compact steps reads a flag back (a stream synchronisation): a step captured BEFORE any eager
+    step must not run it inside the capture -- it steps at full width instead, with the same results."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    outs = []
+    for mode in ("eager", "graph"):
+        wl = make_mult_slice_workload(200, dev, n_scenarios=8, n_traces=4, trace_len=12, max_steps=1000)
+        env = wl.env
+        env.reset(); torch.cuda.synchronize()
+        if mode == "eager":
+            for _ in range(5):
+                env.step()
+        else:
+            g = _captured_step_graph(env, dev)
+            for _ in range(5):
+                g.replay()
+        torch.cuda.synchronize()
+        v = env.views()
+        outs.append((env.obs_inter.clone(), env.reward.clone(), v["queue_pkts"].clone(), v["step_number"].clone(), v["win_sent"].clone()))
+        env.close()
+    assert int(outs[1][3].min()) == 5
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
