@@ -46,6 +46,9 @@
 
 #define DEVFN __device__ __forceinline__
 
+#ifndef RANENV_FAST_DIV
+#define RANENV_FAST_DIV 1   /* 0: every f64 division through the plain operator (A/B and the parity check of ddiv itself) */
+#endif
 #ifndef RANENV_DIAG
 #define RANENV_DIAG 0   /* diagnostic builds only: 1-5 skip phases of the step kernel, 9 stamps s_memtime at its
                            phase boundaries (tools/stamps.py) */
@@ -148,6 +151,7 @@ struct PersistCtl {
 struct KP {
     int B, S, U, R, G, Us, D, L, max_steps, flags, policy, fixed_intra;
     long long BU, NSU, NSL;   // slab strides: B*U, n_scenarios*U, n_scenarios*S*16
+    int T;    // R / G: allocation units of the inter-slice split (an integer division costs a wave ~60 instructions: made once, on the host)
     int e0;   // first env of this launch
     int n_tti;       // TTIs this launch steps every env through (>= 1; more than one only inside ranenv_rollout)
     int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
@@ -194,6 +198,29 @@ struct KP {
 // numpy arithmetic on the device
 // ---------------------------------------------------------------------------------------------
 DEVFN bool d_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * fabs(b)); }
+
+// a / b, correctly rounded, for operands whose quotient needs no scaling: the compiler's f64 division without its three guard
+// instructions (v_div_scale x 2 -- they return their operands unchanged unless an exponent sits near the ends of the range --, and
+// v_div_fixup, which passes the quotient through unless an operand is 0 / inf / nan / denormal): reciprocal estimate, two Newton
+// steps, quotient, one residual correction -- the same instructions in the same order, so the same bits.  8 instead of 11 vector
+// instructions, and the step kernel makes ~30 divisions per wave and TTI.  Only where the divisor is a positive normal number
+// whenever the result is USED (packet sizes, counts, sums guarded by the caller; magnitudes 1e-9...1e12); the intent-drift formulas
+// and the means that may be 0 / 0 in the reference too keep the plain operator.
+DEVFN double ddiv(double a, double b)
+{
+#if RANENV_FAST_DIV
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    const double q = a * r;
+    const double res = fma(-b, q, a);
+    return fma(res, r, q);
+#else
+    return a / b;
+#endif
+}
 
 // numpy pairwise_sum of n <= 16 doubles: missing elements count as +0.0, which turns numpy's three
 // shapes for n <= 16 (n < 8 plain loop; 8 <= n < 16 tree of the first 8 + sequential tail; n == 16
@@ -273,6 +300,17 @@ DEVFN double row16_sum_f64(double x)  // the same for a double (two 32-bit moves
     };
     x += rot(x, std::integral_constant<int, 0x121>{}); x += rot(x, std::integral_constant<int, 0x122>{});
     x += rot(x, std::integral_constant<int, 0x124>{}); x += rot(x, std::integral_constant<int, 0x128>{});
+    return x;
+}
+DEVFN double row16_max_f64(double x)  // every lane gets the maximum of its row (no NaNs here: comparisons and v_max agree)
+{
+    auto rot = [](double v, auto ctrl) {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = dpp_row<decltype(ctrl)::value>((int)b), hi = dpp_row<decltype(ctrl)::value>((int)(b >> 32));
+        return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    };
+    x = fmax(x, rot(x, std::integral_constant<int, 0x121>{})); x = fmax(x, rot(x, std::integral_constant<int, 0x122>{}));
+    x = fmax(x, rot(x, std::integral_constant<int, 0x124>{})); x = fmax(x, rot(x, std::integral_constant<int, 0x128>{}));
     return x;
 }
 DEVFN double wave_sum_f64(double x)   // sum over the 64 lanes of the wave (all active): rows by DPP, then the four row sums
@@ -735,7 +773,8 @@ struct SharedCore {
     int si[NP][8];                // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
     int pi[NP][6];                // (metric, op) x 3
     int cnt[NP][NP + 4];          // RBs of each slot (padded like rows)
-    unsigned char flg[NP][NP + 6];    // buffer-not-empty flag of each slot
+    unsigned msk[NP][2];              // per slice, one bit per UE position, set with LDS atomic ORs by the slice's UEs and read as ONE word:
+                                      // [0] the UE's buffer is not empty, [1] its PF / MT value is non-zero.  All zero between two allocations
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
 #if RANENV_OBS_STAGE
     // this TTI's observation rows, staged here and written out by wave 0 as whole lines: written one float per lane and
@@ -813,10 +852,11 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
     double *r0 = srow(sh, sl, 0), *r1 = srow(sh, sl, 1), *r2 = srow(sh, sl, 2), *r3 = srow(sh, sl, 3);
     int choice = p.fixed_intra;                    // requested now, used after the inter-slice part
     if (choice == RANENV_INTRA_PER_SLICE) choice = (p.intra && have) ? (int)p.intra[(size_t)e * S + sl] : RANENV_INTRA_RR;
-    const double occ = (double)q / (double)mp;
-    const double hm = hlen > 0 ? (double)wsent / (double)hlen : 0.0;
+    const double occ = ddiv((double)q, (double)mp);
+    const double hm = hlen > 0 ? ddiv((double)wsent, (double)hlen) : 0.0;
     const bool has_pkts = have && !d_isclose(occ, 0.0);
-    if (have) { r0[pos] = occ; r1[pos] = hm; sh.flg[sl][pos] = has_pkts ? 1 : 0; }
+    if (have) { r0[pos] = occ; r1[pos] = hm; }
+    if (has_pkts) atomicOr(&sh.msk[sl][0], 1u << pos);
     wg_sync(narrow);
 
     // ---- inter-slice: lane t < 16 of wave 0 is slice t ----------------------------------------------
@@ -834,9 +874,9 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
                 double v2 = 0.0;
                 if (tid < 2 * GRP && sl2 < S && sh.si[sl2][0] != 0) {
                     const int n2 = sh.si[sl2][2];
-                    v2 = np_sum_lds<NP>(srow(sh, sl2, half), n2) / (double)n2;
+                    v2 = ddiv(np_sum_lds<NP>(srow(sh, sl2, half), n2), (double)n2);
                     if (half == 0) v2 = v2 * (double)sh.si[sl2][3];                     // x buffer size
-                    v2 = (v2 * (double)sh.si[sl2][5]) / 1e6;                            // x message size, to Mbit
+                    v2 = ddiv(v2 * (double)sh.si[sl2][5], 1e6);                         // x message size, to Mbit
                 }
                 if (tid < 2 * GRP) xs[half][sl2] = v2;
             }
@@ -845,17 +885,17 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             if (tid < GRP) { occ_mb = xs[0][s1]; thr_mb = xs[1][s1]; }
             double w = 0.0;
             if (tid < GRP) {
-                double mx = xs[0][0];
-#pragma unroll
-                for (int j = 1; j < NP; j++) { const double v = xs[0][j]; mx = (j < S && v > mx) ? v : mx; }
-                w = d_isclose(thr_mb, 0.0) ? 2.0 * mx : occ_mb / thr_mb;                            // :91-100
+                // the largest backlog over the slices (np.max over all S entries): every slice lane holds its own, a DPP row maximum
+                // instead of ten LDS reads and compares per lane
+                const double mx = row16_max_f64(s1 < S ? occ_mb : -__builtin_inf());
+                w = d_isclose(thr_mb, 0.0) ? 2.0 * mx : ddiv(occ_mb, thr_mb);                       // :91-100
                 if (!active) w = 0.0;
                 xs[2][s1] = ok1 ? w : 0.0;
             }
             wave_sync();
             if (tid < GRP) {
                 const double ws = np_sum_lds<NP>(xs[2], S);
-                score = (ws > 0.0 ? w / ws : 2.0) - 1.0;                                            // :105-109
+                score = (ws > 0.0 ? ddiv(w, ws) : 2.0) - 1.0;                                       // :105-109
             }
             wave_sync();
         } else if (ok1) {
@@ -866,7 +906,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
 #endif
         if (tid < GRP) xs[3][s1] = score;
         wave_sync();
-        const int T = p.R / p.G;
+        const int T = p.T;
         double my_a = -1.0;
         if (tid < GRP) {
             my_a = (ok1 && active) ? xs[3][sorted] : -1.0;                                           // ib_sched.py:247-255
@@ -877,7 +917,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
         if (tid < GRP) {
             // np.sum(association) adds small integers: exact in any order, so an integer row sum does it
             const double ssum = np_sum_lds<NP>(xs[0], S), asum = (double)row16_sum(ok1 ? active : 0);
-            if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? (double)T * (my_a + 1.0) / ssum : ((double)T / asum) * (double)active;
+            if (ok1 && asum != 0.0) my_v = ssum != 0.0 ? ddiv((double)T * (my_a + 1.0), ssum) : ddiv((double)T, asum) * (double)active;
             nzf = my_v != 0.0;
             // compaction of the non-zero values in slice order (common.py:484-485): they move to the front,
             // the zeros fill the slots behind them: every slot is written exactly once
@@ -889,7 +929,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
         wave_sync();
         if (tid < GRP) {
             const double tot = np_sum_lds<NP>(xs[2], m_nz);
-            const int my_prop = nzf ? (int)((double)T * my_v / tot) : 0;                  // :488-490 (value >= 0)
+            const int my_prop = nzf ? (int)ddiv((double)T * my_v, tot) : 0;               // :488-490 (value >= 0)
             const int acc = row16_sum(my_prop);
             const int adj = T - acc;                                                     // :493-499
             int extra = 0;
@@ -922,8 +962,8 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
     if (!all_rr) {
         double avail = 0.0;                      // evaluated by every slice (a per-slice choice may need it)
         if (have) {
-            const double slice_bw = (double)n_rbs * p.bw_hz / (double)p.R;             // common.py:573-578
-            const double cap = sem * slice_bw / (double)n;
+            const double slice_bw = ddiv((double)n_rbs * p.bw_hz, (double)p.R);         // common.py:573-578
+            const double cap = ddiv(sem * slice_bw, (double)n);
             const double backlog = occ * (double)mp * (double)pk;
             avail = cap < backlog ? cap : backlog;
             r0[pos] = avail;                     // (the occupancy row was consumed by the inter-slice part)
@@ -940,26 +980,25 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
 #pragma unroll
                 for (int k = 1; k < NP; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
             }
-            num = starved ? 2.0 * max_avail : avail / snt;
+            num = starved ? 2.0 * max_avail : ddiv(avail, snt);
         }
         if (have) r1[pos] = num;
         wg_sync(narrow);
         const double wsum = np_sum_lds<NP>(r1, n);
         use_round = n > 0 && wsum != 0.0 && choice != RANENV_INTRA_RR;                 // :603-608
-        my_val = (use_round && have) ? (double)n_rbs * num / wsum : 0.0;
-        if (have) r2[pos] = my_val;
-        wg_sync(narrow);
-        unsigned gmv = 0;                        // which positions of the slice hold a non-zero value
-#pragma unroll
-        for (int k = 0; k < NP; k++) gmv |= (r2[k] != 0.0) ? (1u << k) : 0u;
+        my_val = (use_round && have) ? ddiv((double)n_rbs * num, wsum) : 0.0;
         nzv = my_val != 0.0;
+        if (have) r2[pos] = my_val;
+        if (have && nzv) atomicOr(&sh.msk[sl][1], 1u << pos);
+        wg_sync(narrow);
+        const unsigned gmv = sh.msk[sl][1];      // which positions of the slice hold a non-zero value
         m_v = __popc(gmv);
         const int slot_v = nzv ? __popc(gmv & below) : m_v + __popc(~gmv & below & 0xffffu);
         if (have) r3[slot_v] = my_val;                                                 // compaction (:484-485); zeros go behind
         wg_sync(narrow);
         if (use_round) {
             const double tot = np_sum_lds<NP>(r3, m_v);
-            prop = nzv ? (int)((double)n_rbs * my_val / tot) : 0;                      // floor of a value >= 0
+            prop = nzv ? (int)ddiv((double)n_rbs * my_val, tot) : 0;                   // floor of a value >= 0
         }
     }
     if (!all_rr) {
@@ -983,9 +1022,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
         }
     } else {
         // round_robin; the buffer filter applies only when RR is the slice's own choice (:508-555, :609-617)
-        unsigned gmr = 0;
-#pragma unroll
-        for (int k = 0; k < NP; k++) gmr |= sh.flg[sl][k] != 0 ? (1u << k) : 0u;
+        unsigned gmr = sh.msk[sl][0];
         if (choice != RANENV_INTRA_RR) gmr = 0u;
         int k_sel = __popc(gmr), idx = __popc(gmr & below);
         const bool all = (k_sel == 0);
@@ -998,6 +1035,7 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
     if (!all_rr) wg_sync(narrow);                                                  // every prop was read
     if (have) sh.cnt[sl][pos] = count;
     wg_sync(narrow);
+    if (have && pos == 0) { sh.msk[sl][0] = 0u; sh.msk[sl][1] = 0u; }              // (both masks were read in front of that barrier; the next ORs are barriers away)
     int before = 0;                                                                // :464-478 contiguous ranges
 #pragma unroll
     for (int k = 0; k < NP; k++) before += k < pos ? sh.cnt[sl][k] : 0;
@@ -1246,7 +1284,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             const int sl0 = i / (4 * NP), rem = i - sl0 * (4 * NP), k0 = rem / NP, j0 = rem - k0 * NP;
             sh.rows[sl0][k0 * NP + j0] = 0.0;
         }
-        for (int i = tid; i < S * NP; i += LW) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; sh.flg[sl0][j0] = 0; }
+        for (int i = tid; i < S * NP; i += LW) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; }
+        if (tid < S * 2) (&sh.msk[0][0])[tid] = 0u;
         if (tid < S * 8) (&sh.si[0][0])[tid] = st_si0;
         if (tid + LW < S * 8) (&sh.si[0][0])[tid + LW] = st_si1;
         if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi0;
@@ -1346,15 +1385,15 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
                 if (mrow[r] != 0) { rb_count++; if (!seen) { rb_start = r; seen = true; } }
             }
         }
-        const double se_mean_new = GATHER ? sem_tile : my_full / (double)R, se_part = my_part;
+        const double se_mean_new = GATHER ? sem_tile : ddiv(my_full, (double)R), se_part = my_part;
         int dropped = 0, sent = 0, pkt_in = 0, pkt_thr = 0;     // all < 2^31 (host validates the packet counts)
         int adm_now = 0;                                        // packets admitted at this TTI (its age-list entry, if any)
         if (MODE != MODE_RESET) {
             const double psz = (double)pkt_size;
             // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
             if (gen_traffic && !CARRY) traffic = draw_traffic();
-            pkt_thr = (int)((se_part * COLD(bw_per_rb)) / psz);
-            pkt_in = (int)(traffic / psz);
+            pkt_thr = (int)ddiv(se_part * COLD(bw_per_rb), psz);
+            pkt_in = (int)ddiv(traffic, psz);
             const int L = p.L;
             // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of (arrival TTI,
             // packets) entries in arrival order.  ring[k] holds entry k of a circular list (head index +
@@ -1472,8 +1511,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             }
             cy.pf_old_s = ps; cy.pf_old_d = pd; cy.pf_traffic = pt; cy.pf1 = e1; cy.pf2 = e2;
         }
-        const double occ_new = (double)total / (double)max_pkts;
-        const double lat_new = total > 0 ? (double)sum_age / (double)total : 0.0;
+        const double occ_new = ddiv((double)total, (double)max_pkts);
+        const double lat_new = total > 0 ? ddiv((double)sum_age, (double)total) : 0.0;
         // ---- intent drift of this UE (agents/common.py:68-340) ----------------------------------------
         // The slice lists up to three parameters in its own order; the lanes of a wave belong to different
         // slices, so "for each parameter: switch on its metric" would run all three formulas three times.
@@ -1508,7 +1547,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             // on the selected operands gives the bits of whichever arm is taken.
             if (dec[RANENV_METRIC_THROUGHPUT]) {
                 const double value = val[RANENV_METRIC_THROUGHPUT];
-                double x = ((double)sent * (double)msg) / 1e6;                          // common.py:25-31
+                double x = ddiv((double)sent * (double)msg, 1e6);                       // common.py:25-31
                 bool zero = d_isclose(occ_new, 0.0);                                    // :100-119
                 if (hlen_new > 1) zero = zero || prev_empty;
                 if (zero) x = value * (1.1 + o);
@@ -1547,7 +1586,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
                 float *oa = COLD(obs_intra) + ((size_t)e * S + slc) * W;
 #endif
                 oa[9 + ue_pos] = (float)occ_new;
-                oa[9 + Us + ue_pos] = (float)(se_mean_new / COLD(norm_se));
+                oa[9 + Us + ue_pos] = (float)ddiv(se_mean_new, COLD(norm_se));
             }
         }
     }
@@ -1594,7 +1633,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         int s4 = 0, n4 = 0;
         if (sp4 < S) { s4 = sh.si[sp4][7]; n4 = sh.si[s4][2]; }
         const double sum4 = np_sum_lds<NP>(srow(sh, s4, row4), n4);
-        if (n4 > 0) mean4 = sum4 / (double)n4;
+        if (n4 > 0) mean4 = ddiv(sum4, (double)n4);
         xr[row4][sp4] = mean4;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1640,7 +1679,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         const double se_slice = n > 0 ? mean_row[3] : 0.0;                                      // :146-157
         const float o0 = (float)sv[0], o1 = (float)sv[1], o2 = (float)sv[2];
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
-        const float tr = (float)(traffic_req / COLD(norm_traffic)), nu = (float)((double)n / COLD(norm_ues));
+        const float tr = (float)ddiv(traffic_req, COLD(norm_traffic)), nu = (float)ddiv((double)n, COLD(norm_ues));
         if (COLD(obs_inter)) {                                                         // :160-173
 #if RANENV_OBS_STAGE
             float *oi = sh.ob_inter + spos * 10;
@@ -1648,7 +1687,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             float *oi = COLD(obs_inter) + ((size_t)e * S + spos) * 10;
 #endif
             oi[0] = o0; oi[1] = o1; oi[2] = o2; oi[3] = a0; oi[4] = a1; oi[5] = a2;
-            oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)(se_slice / COLD(norm_se));
+            oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)ddiv(se_slice, COLD(norm_se));
         }
         if (COLD(obs_intra)) {
 #if RANENV_OBS_STAGE
@@ -1657,7 +1696,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             float *oa = COLD(obs_intra) + ((size_t)e * S + s) * W;
 #endif
             oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
-            oa[6] = (float)((double)rbs_s / (double)R); oa[7] = tr; oa[8] = nu;
+            oa[6] = (float)ddiv((double)rbs_s, (double)R); oa[7] = tr; oa[8] = nu;
             for (int k = n; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
         }
         // player_{s+1} reward (common.py:428-437)
@@ -3211,6 +3250,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         return fail(nullptr, RANENV_E_INVALID,
                     "unsupported sizes: need 1<=S<=16, 1<=U<=256, 1<=R<=512, 1<=Us<=16, 1<=G<=R, 1<=hist_depth<=64");
     if (!(cfg->bandwidth_hz > 0.0)) return fail(nullptr, RANENV_E_INVALID, "bandwidth_hz must be positive");
+    if (!(cfg->norm_traffic > 0.0) || !(cfg->norm_ues > 0.0) || !(cfg->norm_se > 0.0))
+        return fail(nullptr, RANENV_E_INVALID, "norm_traffic, norm_ues, norm_se (the observation's normalisers, agents/ib_sched.py:166-168) must be positive");
     if (R > 128) {   // the row reduction follows numpy's pairwise split two levels deep: every leaf must be <= 128 RBs
         int n2 = R / 2; n2 -= n2 % 8;
         const int halves[2] = {n2, R - n2};
@@ -3235,7 +3276,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     KP &kp = h->kp;
     memset(&kp, 0, sizeof(kp));
     kp.B = cfg->batch; kp.S = S; kp.U = U; kp.R = R; kp.G = cfg->rbs_per_rbg; kp.Us = Us; kp.D = cfg->hist_depth;
-    kp.L = (int)L; kp.max_steps = cfg->max_steps; kp.flags = cfg->flags;
+    kp.L = (int)L; kp.max_steps = cfg->max_steps; kp.flags = cfg->flags; kp.T = R / cfg->rbs_per_rbg;
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
     kp.late = RANENV_LATE_DEFAULT;
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
