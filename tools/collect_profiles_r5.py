@@ -27,7 +27,7 @@ for mode in ("stream", "gather"):
     if os.path.exists(kt):
         with open(f"profiles/r05_{mode}_kernel_launches.txt", "w") as out:
             out.write(f"# every launch of this library's kernels in `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 "
-                      f"{'--only-gather' if mode == 'gather' else '--no-single-stream --no-gather'} --no-cpu-baseline`, in start order: "
+                      f"{'--only-gather' if mode == 'gather' else '--no-single-stream --no-gather'} --no-other-configs --no-cpu-baseline`, in start order: "
                       "duration ms, block threads, workgroups, kernel\n")
             for r in csv.DictReader(open(kt)):
                 if "ranenv_" in r["Kernel_Name"]:
@@ -43,4 +43,14 @@ for mode in ("stream", "gather"):
 for a, b in (("r05_pmc.json", "r05_pmc.json"), ("pmc_stream_summary.txt", "r05_pmc_sq_stream.txt"), ("pmc_gather_summary.txt", "r05_pmc_sq_gather.txt")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join("profiles", b))
+kt20 = os.path.join(src, "prof_stream_k20/p_kernel_trace.csv")
+if os.path.exists(kt20):          # what a 20-TTI block (the driver's --steps 20) spends outside the steady state
+    import subprocess
+    steady = None
+    for ln in open(os.path.join(src, "bench.log")):
+        if ln.startswith("{"):
+            steady = json.loads(ln)["ms_per_step"] * 1e3
+    out = subprocess.run([sys.executable, "tools/block_timeline.py", kt20, "20"] + ([f"{steady:.3f}"] if steady else []), capture_output=True, text=True).stdout
+    open("profiles/r05_block_timeline_k20.txt", "w").write("# tools/block_timeline.py on `rocprofv3 --kernel-trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+                                                           "--no-single-stream --no-gather --no-other-configs`\n" + out)
 print("profiles updated from", src, "->", sorted(lines))

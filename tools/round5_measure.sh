@@ -32,8 +32,9 @@ python3 tools/pmc_collect_r4.py $out/r05_pmc.json 4096 2 \
   gather_rollout:$TT:$out/pmc_gather_FETCH_SIZE,$out/pmc_gather_WRITE_SIZE,$out/pmc_gather_sq,$out/pmc_gather_sq2 > $out/pmc_collect.log
 python3 tools/pmc_summary.py $out/pmc_stream_sq $out/pmc_stream_sq2 > $out/pmc_stream_summary.txt
 python3 tools/pmc_summary.py $out/pmc_gather_sq $out/pmc_gather_sq2 > $out/pmc_gather_summary.txt
-step prof_stream 400 rocprofv3 --kernel-trace --stats -d $out/prof_stream -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --no-single-stream --no-gather
-step prof_gather 400 rocprofv3 --kernel-trace --stats -d $out/prof_gather -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --only-gather
+step prof_stream 400 rocprofv3 --kernel-trace --stats -d $out/prof_stream -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --no-single-stream --no-gather --no-other-configs
+step prof_stream_k20 400 rocprofv3 --kernel-trace --stats -d $out/prof_stream_k20 -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-stream --no-gather --no-other-configs
+step prof_gather 400 rocprofv3 --kernel-trace --stats -d $out/prof_gather -o p --output-format csv -- python3 bench.py --steps 200 --no-cpu-baseline --only-gather --no-other-configs
 step bench_cfg1 300 python3 bench.py --config 1 --no-cpu-baseline
 step bench_cfg4 300 python3 bench.py --config 4 --no-cpu-baseline
 step bench_native 400 python3 bench.py --config native --no-cpu-baseline
