@@ -277,7 +277,7 @@ def _partition_bounds(B, parts, unit=1):
     return lo
 
 
-def _mirror_rollouts_with_the_oracle(wl, sample, calls, se_mode, where, after_call=None):
+def _mirror_rollouts_with_the_oracle(wl, sample, calls, se_mode, where, after_call=None, traffic_of=None):
     """The bench schedule of `wl` (whatever its options select) against the CPU oracle: the envs in `sample` are mirrored by
     pyoracle.OracleEnv under the workload's own device policy (MARR agents/marr.py:40-47 / MAPF agents/mapf.py:41-111, scores from the
     oracle's own state, simu.py:555-566) and intra-slice scheduler (agents/common.py:508-636) and compared after every
@@ -308,8 +308,8 @@ def _mirror_rollouts_with_the_oracle(wl, sample, calls, se_mode, where, after_ca
             after_call(k)
         for _ in range(k):
             for b, o in oenvs.items():
-                o.step(score(o), intra, se_host[tpos[int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)]],
-                       trf_host[int(eps["trf_base"][b] + (eps["trf_offset"][b] + t) % L)])
+                bits = traffic_of(b, t) if traffic_of is not None else trf_host[int(eps["trf_base"][b] + (eps["trf_offset"][b] + t) % L)]
+                o.step(score(o), intra, se_host[tpos[int(eps["se_base"][b] + (eps["se_offset"][b] + t) % L)]], bits)
             t += 1
         torch.cuda.synchronize()
         _compare_with_oracle(env, oenvs, max_pkts, (where, se_mode, "after TTI", t))
@@ -331,6 +331,25 @@ def test_config2_headline_schedule_vs_oracle(se_mode):
     sample, members = _headline_sample(wl)
     assert len(sample) >= 32 and (members[sample] <= 64).sum() >= 12 and (members[sample] > 64).sum() >= 12
     _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[2]")
+    env.close()
+
+
+def test_config2_headline_schedule_with_the_device_traffic_generator_vs_oracle():
+    """`bench.py --traffic philox`: the headline schedule with the offered traffic drawn on the device (Poisson by table inversion of
+    Philox-4x32-10 keyed (seed; env, episode, TTI, UE), traffics/mult_slice.py:24-32 in distribution); the oracle is fed the numpy
+    restatement's draws for the mirrored envs."""
+    _need_gpu()
+    from oracle import pyoracle
+    from intent_radio_sched_multi_slice_amd.workloads import make_bench_workload
+    wl, _ = make_bench_workload(2, torch.device("cuda", 0), n_traces=64, trace_len=80, traffic="philox")
+    env = wl.env
+    env.set_partitions(3)
+    _bench_options(env)
+    sample, members = _headline_sample(wl, per_class=4)
+    cdf, _ = env.poisson_tables()
+    seed = 1234                                                    # make_bench_workload: set_traffic_generator(seed=1234 + rank), env ids from 0
+    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS[:6], "stream", "configs[2] philox",
+                                     traffic_of=lambda b, t: pyoracle.generator_traffic(cdf, wl.tables, int(wl.scenario[b]), seed, b, 0, t))
     env.close()
 
 
