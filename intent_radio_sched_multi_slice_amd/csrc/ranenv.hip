@@ -1986,7 +1986,10 @@ template <typename P> DEVFN int persist_finish(const P &p, PersistLocal &pl, int
 {
     PersistCtl *c = p.p_ctl;
     if (done >= n_tti) return 0;
-    if (pq_ldi(&c->abort) != 0) return 0;
+    if (pq_ldi(&c->abort) != 0) {        // a wait gave up somewhere in this class: the env is dropped here, and the host is told (again)
+        if (p.p_err) __hip_atomic_store(p.p_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return 0;
+    }
     const int fresh = persist_try_fresh(p, pl);
     if (fresh == PERSIST_NONE) {
         if (pq_ldi(&c->q[pl.xcc].avail) <= 0) { PSTAT(0); return 1; }    // nobody is waiting
@@ -2605,6 +2608,7 @@ struct ranenv {
     bool pclass_maybe = false;     // an auto-reset ran since the lists were built: they are stale IF an env restarted (the device knows:
     int *d_cls_flag = nullptr;     // ... this word, set by ranenv_advance_kernel, tested and cleared by the classify kernel)
     int *h_perr = nullptr;         // sticky error word of the persistent launches, in host memory the device can write (a wait gave up)
+    int *d_perr_dev = nullptr;     // ... its address as the device sees it
     int perr_seen = 0;             // ... what of it has been reported
     int persist_inject = 0;        // test hook (option "persist_inject_abort"): the next persistent launch finds its abort word set
     int last_rollout_persistent = 0, last_rollout_launches = 0;   // what the last ranenv_rollout call ran (read-only options)
@@ -3051,6 +3055,7 @@ int persist_prepare(ranenv_handle h, hipStream_t stream, bool need_host_counts)
         // the sticky error word lives in host memory the device can write: the host looks at it without a device sync
         HIP_TRY(h, hipHostMalloc((void **)&h->h_perr, sizeof(int), hipHostMallocMapped));
         *h->h_perr = 0;
+        HIP_TRY(h, hipHostGetDevicePointer((void **)&h->d_perr_dev, h->h_perr, 0));       // (the same address with unified addressing; asked for, not assumed)
         h->pcount_host.assign((size_t)NC, 0);
         h->pclass_dirty = true;
     }
@@ -3100,7 +3105,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
     const int B = h->cfg.batch, NC = h->p_nclass;
     const bool gather = h->se_mode == RANENV_SE_GATHER;
     kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0;
-    kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->h_perr;
+    kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->d_perr_dev;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
         kp.se_mean_pool = h->d_se_mean; kp.se_rp = h->se_rp;
@@ -3146,8 +3151,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
         if (h->persist_inject) {                   // test hook: this launch finds a wait already given up
             const int one = 1;
-            HIP_TRY(h, hipMemcpyAsync(&kc.p_ctl->abort, &one, sizeof(int), hipMemcpyHostToDevice, s));
-            *(volatile int *)h->h_perr = 1;
+            HIP_TRY(h, hipMemcpyAsync(&kc.p_ctl->abort, &one, sizeof(int), hipMemcpyHostToDevice, s));      // (the DEVICE then raises the host-visible word)
         }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (h->prof_on) {
