@@ -368,7 +368,12 @@ int ranenv_set_max_steps(ranenv_handle h, const int32_t *host_max_steps, void *s
  *   ranenv_autoreset          enqueue after a step: every env with dev_done != 0 gets its terminal observation
  *                             copied to the term_* buffers (each may be NULL), the next episode's descriptor
  *                             installed and CommunicationEnv.reset applied (obs_* receive the new episode's first
- *                             observation; the step's rewards and done flags are left as they are).  No host sync. */
+ *                             observation; the step's rewards and done flags are left as they are).  No host sync.
+ *                             `done` is a function of the env's step counter alone (step >= its episode length) and the host
+ *                             follows the counters from a reset of the whole batch on: when dev_done is the buffer the last
+ *                             step wrote and no episode ended at that TTI, the call enqueues NOTHING (an RL loop calls it
+ *                             behind every step).  Flags the host cannot follow -- another buffer, a caller's masked reset
+ *                             before, a stream capture -- are left to the device as before. */
 int ranenv_set_episode_table(ranenv_handle h, const ranenv_episode *host_table, int32_t first_episode,
                              int32_t n_episodes, void *stream);
 int ranenv_set_autoreset(ranenv_handle h, int32_t enable, int32_t initial_episode, int32_t max_episode,

@@ -2584,6 +2584,13 @@ struct ranenv {
     uint8_t *d_ar_mask = nullptr;
     double *d_acc = nullptr, *d_ep_acc = nullptr; int32_t *d_ep_n = nullptr; int ep_slots = 0;   // ranenv_enable_metrics
     std::vector<int32_t> host_max_steps;        // copy of ranenv_set_max_steps' array (the multi-episode rollout follows the step counters)
+    // Host shadow of the per-env step counters (what they will be once everything enqueued so far has run): `done` is a function of
+    // the counter alone (step >= the env's episode length), so ranenv_autoreset knows WITHOUT reading anything back whether an episode
+    // ended at the TTI just enqueued -- and enqueues nothing when none did (an RL loop calls it behind every step: three small launches
+    // = 7 us per TTI saved, profiles/r05_ab_log.txt).  Valid from a reset of the whole batch until something the host cannot follow
+    // (a masked reset by the caller).
+    std::vector<int32_t> sh_steps; bool sh_valid = false;
+    const uint8_t *last_done = nullptr;         // the `done` buffer the steps write (the shortcut applies to that buffer only)
     unsigned long long *d_pois_cdf = nullptr; uint8_t *d_pois_guide = nullptr; int32_t *d_max_steps = nullptr;
     std::vector<double> slice_traffic;          // [NS][S] host copy (traffic generator tables)
     std::vector<int32_t> slice_has_req;
@@ -2976,6 +2983,28 @@ AdvanceArgs advance_args(ranenv_handle h, const uint8_t *dev_done, float *obs_in
 }
 
 int max_steps_of_env(ranenv_handle h, int b) { return h->host_max_steps.empty() ? h->cfg.max_steps : h->host_max_steps[(size_t)b]; }
+
+void shadow_steps_add(ranenv_handle h, int lo, int hi, int n, const uint8_t *done, hipStream_t stream)      // n TTIs enqueued for envs [lo, hi)
+{
+    if (done) h->last_done = done;
+    if (!h->sh_valid) return;
+    if (stream_capturing(stream)) { h->sh_valid = false; return; }       // (a graph may be replayed any number of times)
+    int32_t *s = h->sh_steps.data();
+    for (int b = lo; b < hi; b++) s[b] += n;
+}
+// envs of [lo, hi) whose episode ended at the TTI enqueued last: -1 = unknown (ask the device), else how many
+int shadow_due(ranenv_handle h, int lo, int hi, const uint8_t *dev_done, hipStream_t stream)
+{
+    if (!h->sh_valid || dev_done == nullptr || dev_done != h->last_done || stream_capturing(stream)) return -1;
+    int due = 0;
+    for (int b = lo; b < hi; b++) due += h->sh_steps[(size_t)b] >= max_steps_of_env(h, b) ? 1 : 0;
+    return due;
+}
+void shadow_reset_due(ranenv_handle h, int lo, int hi)      // the auto-reset that was just enqueued restarts exactly those envs
+{
+    if (!h->sh_valid) return;
+    for (int b = lo; b < hi; b++) if (h->sh_steps[(size_t)b] >= max_steps_of_env(h, b)) h->sh_steps[(size_t)b] = 0;
+}
 
 // ---- persistent rollout (option "persist"), host side ------------------------------------------------------------
 hipError_t ensure_streams(ranenv_handle h, size_t n)      // handle-owned streams / events [1, n) exist (index 0 = the caller's stream)
@@ -3617,6 +3646,8 @@ int ranenv_reset(ranenv_handle h, const uint8_t *env_mask, const float *se_tiles
     hipError_t e = launch<MODE_RESET>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "reset launch: %s", hipGetErrorString(e));
     if (env_mask == nullptr) h->idle_state_clean = true;        // every queue of the batch is empty again
+    if (env_mask == nullptr) { h->sh_steps.assign((size_t)h->cfg.batch, 0); h->sh_valid = true; }
+    else h->sh_valid = false;                                   // (which envs restart is on the device)
     return RANENV_OK;
 }
 
@@ -3634,6 +3665,7 @@ int ranenv_step(ranenv_handle h, const double *scores, const uint8_t *intra, con
     if (rc != RANENV_OK) return rc;
     hipError_t e = launch<MODE_STEP>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "step launch: %s", hipGetErrorString(e));
+    shadow_steps_add(h, 0, h->cfg.batch, 1, done, (hipStream_t)stream);
     return RANENV_OK;
 }
 
@@ -3651,6 +3683,7 @@ int ranenv_step_dense(ranenv_handle h, const uint8_t *dense, const double *traff
     h->idle_state_clean = false;                 // (a dense decision is the facade's path: explicit traffic, any UE)
     hipError_t e = launch<MODE_DENSE>(h, kp, (hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "dense step launch: %s", hipGetErrorString(e));
+    shadow_steps_add(h, 0, h->cfg.batch, 1, done, (hipStream_t)stream);
     return RANENV_OK;
 }
 
@@ -3673,6 +3706,7 @@ int ranenv_step_range(ranenv_handle h, int32_t env_first, int32_t env_count, con
     hipError_t e = launch_range<MODE_STEP>(h, kp, env_first, env_count, (hipStream_t)stream);
     if (e == hipSuccess && (h->cfg.flags & RANENV_F_SYNC_CHECK)) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return fail(h, RANENV_E_HIP, "step launch (envs [%d,%d)): %s", env_first, env_first + env_count, hipGetErrorString(e));
+    shadow_steps_add(h, env_first, env_first + env_count, 1, done, (hipStream_t)stream);
     return RANENV_OK;
 }
 
@@ -3978,6 +4012,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
             const hipError_t re = launch_range<MODE_RESET>(h, kpr, 0, h->cfg.batch, stream);
             if (re != hipSuccess) return fail(h, RANENV_E_HIP, "persistent rollout, reset launch: %s", hipGetErrorString(re));
         }
+        if (follow) { h->sh_steps = steps; h->sh_valid = true; h->last_done = done; }      // (read from the device above, followed exactly since)
+        else shadow_steps_add(h, 0, h->cfg.batch, n_steps, done, stream);
         return RANENV_OK;
     }
     // A launch takes its envs through several TTIs where nothing has to happen in between (see step_loop): no head kernel
@@ -4042,6 +4078,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
         if (e != hipSuccess) return fail(h, RANENV_E_HIP, "rollout, round %d of launches: %s", round, hipGetErrorString(e));
         for (int k = 0; k < np; k++) pdone[(size_t)k] += pn[(size_t)k];
     }
+    if (follow) { h->sh_steps = steps; h->sh_valid = true; h->last_done = done; }
+    else shadow_steps_add(h, 0, h->cfg.batch, n_steps, done, stream);
     return RANENV_OK;
 }
 
@@ -4105,6 +4143,7 @@ int ranenv_set_max_steps(ranenv_handle h, const int32_t *host_max_steps, void *s
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    h->sh_valid = false;           // (`done` of a step already enqueued was decided under the old lengths: the shadow restarts at the next full reset)
     if (!host_max_steps) { h->kp.max_steps_env = nullptr; h->host_max_steps.clear(); return RANENV_OK; }
     for (int b = 0; b < h->cfg.batch; b++) if (host_max_steps[b] < 1) return fail(h, RANENV_E_INVALID, "env %d: max_steps must be >= 1", b);
     if (!h->d_max_steps && dev_alloc(h, &h->d_max_steps, (size_t)h->cfg.batch) != RANENV_OK) return RANENV_E_NOMEM;
@@ -4180,6 +4219,13 @@ int ranenv_autoreset(ranenv_handle h, const uint8_t *dev_done, float *obs_inter,
         return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_;
+    // no episode ended at the TTI enqueued last (the host follows the step counters, see ranenv::sh_steps): nothing to enqueue
+    {
+        const int due = shadow_due(h, 0, h->cfg.batch, dev_done, stream);
+        if (due == 0) return RANENV_OK;
+        if (due < 0) h->sh_valid = false;        // (the device decides by flags the host cannot follow: the shadow ends here)
+        else shadow_reset_due(h, 0, h->cfg.batch);
+    }
     const AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
     h->pclass_maybe = true;                      // (scenarios of the restarted envs, if any: the advance kernel sets the device's flag)
     hipLaunchKernelGGL(ranenv_advance_kernel, dim3((unsigned)h->cfg.batch), dim3(64), 0, stream, a);
@@ -4204,11 +4250,20 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
         return fail(h, RANENV_E_STATE, "auto-reset needs a bound SE pool (the reset observes the new episode's first tile)");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     hipStream_t stream = (hipStream_t)stream_, ps = h->part_stream[(size_t)part];
+    const int e0 = h->part_lo[(size_t)part], n = h->part_lo[(size_t)part + 1] - e0;
+    {
+        const int due = stream_capturing(stream) ? -1 : shadow_due(h, e0, e0 + n, dev_done, ps);
+        if (due == 0) {                            // (no episode of this range ended: see ranenv_autoreset)
+            HIP_TRY(h, hipEventRecord(h->part_done[(size_t)part], ps));                    // ranenv_wait_part still finds its event
+            return RANENV_OK;
+        }
+        if (due < 0) h->sh_valid = false;
+        else shadow_reset_due(h, e0, e0 + n);
+    }
     if (stream != ps) {
         HIP_TRY(h, hipEventRecord(h->part_in[(size_t)part], stream));
         HIP_TRY(h, hipStreamWaitEvent(ps, h->part_in[(size_t)part], 0));
     }
-    const int e0 = h->part_lo[(size_t)part], n = h->part_lo[(size_t)part + 1] - e0;
     AdvanceArgs a = advance_args(h, dev_done, obs_inter, obs_intra, term_obs_inter, term_obs_intra, term_obs_head);
     a.e0 = e0;
     h->pclass_maybe = true;

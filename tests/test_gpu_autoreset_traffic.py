@@ -251,3 +251,44 @@ def test_head_vec_env_with_device_autoreset_costs_one_copy_per_step():
             assert not dones.any() and all(i == {} for i in infos)
     assert env.views()["episode_number"].cpu().numpy().tolist() == [(b % 6 + 2) % 6 for b in range(B)]
     venv.close()
+
+
+def test_autoreset_enqueues_nothing_when_no_episode_ended_and_the_same_as_ever_when_one_did():
+    """`done` is a function of the step counter alone, and the host follows the counters (include/ranenv.h, ranenv_autoreset): behind
+    a TTI at which no episode ended the call enqueues nothing; with flags the host cannot follow (another buffer than the steps'
+    `done`) it asks the device as before.  Same state either way, and the launch counts say which path ran."""
+    _need_gpu()
+    import ctypes as C
+    B, steps = 64, 26
+    outs, launches = [], []
+    for follow in (True, False):
+        wl = _small_workload(B, steps)
+        env, tabs = wl.env, wl.tables
+        n_ep = 12
+        ep = np.arange(n_ep)
+        env.set_episode_table(scenario=(ep * 5) % tabs.n_scenarios, se_base=(ep % 4) * wl.trace_len, se_len=wl.trace_len, se_offset=ep % wl.trace_len,
+                              trf_base=((ep * 5) % tabs.n_scenarios) * wl.trace_len, trf_len=wl.trace_len, trf_offset=(ep * 3) % wl.trace_len)
+        env.set_max_steps(np.where(np.arange(B) % 2 == 0, 9, 13).astype(np.int32))       # episodes end at TTIs 9, 13, 18, 26
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep)
+        if not follow:
+            env._autoreset = False                                                     # (the test calls ranenv_autoreset itself, with a COPY of done)
+        env.reset()
+        env.profile_begin()
+        for t in range(steps):
+            env.step()
+            if not follow:
+                mine = env.done.clone()
+                st = env._lib.ranenv_autoreset(env._h, C.c_void_p(mine.data_ptr()), C.c_void_p(env.obs_inter.data_ptr()), C.c_void_p(env.obs_intra.data_ptr()),
+                                               C.c_void_p(env.term_obs_inter.data_ptr()), C.c_void_p(env.term_obs_intra.data_ptr()), None,
+                                               C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream))
+                assert st == 0
+        kms = env.profile_end()
+        launches.append(kms["n_launches"])
+        v = env.views()
+        outs.append({k: v[k].clone() for k in ("queue_pkts", "step_number", "episode_number", "win_sent", "pkt_effective_thr")} | {"obs": env.obs_inter.clone(), "rew": env.reward.clone()})
+        env.close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert int(outs[0]["episode_number"].max()) >= 2
+    assert launches[1] == 2 * steps                       # a step + a masked RESET launch every TTI
+    assert launches[0] == steps + 4, launches             # a RESET launch only behind TTIs 9, 13, 18 and 26
