@@ -403,6 +403,9 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
  *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
  *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one
+ *   "tiny_step"    RANENV_TINY_STEP     1         one-TTI step launches of a batch that stays within 2 waves per SIMD (<= 1024 envs of 100 UEs) run a build with
+ *                                                 the whole SE row and all of the UE's state requested at entry (256 VGPRs): a small batch's step is one chain
+ *                                                 of latencies; 0: the "small_batch" build
  *   "mix"          RANENV_MIX           1         a step launch of the whole batch of two-wave workgroups (64 < U <= 128) runs as MIXED BLOCKS where a
  *                                                 compact step is exact: one block per env of more than 64 slice members, one block per TWO envs
  *                                                 of at most 64 (one wave each) -- the whole batch resident in one round; 0: never, 2: also for

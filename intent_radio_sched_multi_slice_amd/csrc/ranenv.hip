@@ -2112,6 +2112,15 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2,
 #endif
 }
 
+// ... and as an ordinary one-TTI launch for the same batches (env.step() of a small batch: what an SB3 / RLlib trainer with a few hundred envs
+// calls): the whole row requested at entry together with all of the UE's state -- the step is one chain of latencies, and this removes
+// three of the stream's four.
+template <int NP>
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ranenv_core_kernel_tiny1(const KP p)
+{
+    step_loop<MODE_STEP, RANENV_SE_DEPTH_TINY, false, NP, false>(p);
+}
+
 // Sort the envs by the waves a compact step of theirs needs: class c = ceil(slice members of the env's scenario / 64) - 1.
 // ONE workgroup (the counts are built in LDS: no memset in front, one launch in all).  `flag`: a device word that
 // ranenv_advance_kernel sets when an env has restarted -- without `force` the kernel does nothing unless the word is set, and it
@@ -2630,6 +2639,7 @@ struct ranenv {
     int nt = 0;                                 // threads of the core kernel (one per UE, whole waves)
     int np = 16;                                // row width of the step kernel's build: max(S, Us) rounded up to 8, 10 or 16
     int nslot = 0;                              // threads of the head kernel (one per slot, whole waves)
+    int tiny_step = 1;                          // option "tiny_step": one-TTI step launches of a batch at <= 2 waves per SIMD run the whole-row build
     bool small_batch = false;                   // at most 8 workgroups per CU: the 128-VGPR build with the deeper SE queue
     // ranenv_profile_begin / _end: the dispatch's own start / stop timestamps of every step-kernel launch
     // (hipExtLaunchKernel's events: valid with further launches queued behind, unlike events recorded between launches)
@@ -2730,7 +2740,9 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
     return RANENV_OK;
 }
 
-// The build of the step kernel for this handle: SE gather or streaming (lean / small-batch), row width NP.
+bool persist_tiny(ranenv_handle h);
+
+// The build of the step kernel for this handle: SE gather or streaming (lean / small-batch / whole-row), row width NP.
 template <int MODE, int NP, bool MANY>
 void launch_kernels_of(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
 {
@@ -2738,6 +2750,11 @@ void launch_kernels_of(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hip
         if constexpr (MODE != MODE_DENSE) {
             if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
             else hipLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP, MANY>), grid, block, 0, stream, kp);
+        }
+    } else if (MODE == MODE_STEP && !MANY && h->tiny_step && persist_tiny(h)) {      // a batch at <= 2 waves per SIMD: the whole-row build
+        if constexpr (MODE == MODE_STEP && !MANY) {
+            if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_tiny1<NP>), grid, block, 0, stream, ev0, ev1, 0, kp);
+            else hipLaunchKernelGGL((ranenv_core_kernel_tiny1<NP>), grid, block, 0, stream, kp);
         }
     } else if (ev0) {       // (the extended launch costs the host several times an ordinary one: only while profiling)
         if (h->small_batch) hipExtLaunchKernelGGL((ranenv_core_kernel_small<MODE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
@@ -3231,6 +3248,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
         return RANENV_OK;
     }
     if (k == "small_batch") { h->small_batch = v != 0; return RANENV_OK; }
+    if (k == "tiny_step") { h->tiny_step = v != 0 ? 1 : 0; return RANENV_OK; }
     if (k == "persist") { h->persist = v < 0 ? -1 : (v != 0 ? 1 : 0); return RANENV_OK; }
     if (k == "persist_chunk") { h->persist_chunk = v < 1 ? 1 : (v > 1000 ? 1000 : (int)v); return RANENV_OK; }
     if (k == "persist_grid") { h->persist_grid = v < 0 ? 0 : (int)v; return RANENV_OK; }
@@ -3248,7 +3266,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "persist", "persist_chunk", "persist_grid", "pack", "mix"};
+    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "tiny_step", "persist", "persist_chunk", "persist_grid", "pack", "mix"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -3370,6 +3388,7 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     else if (k == "late") *value = h->kp.late;
     else if (k == "row_width") *value = h->np;
     else if (k == "small_batch") *value = h->small_batch ? 1 : 0;
+    else if (k == "tiny_step") *value = h->tiny_step;
     else if (k == "persist") *value = h->persist;
     else if (k == "persist_chunk") *value = h->persist_chunk;
     else if (k == "persist_grid") *value = h->persist_grid;
