@@ -10,7 +10,8 @@
  *   MARLCommEnv(...) construction                   simu.py:348-362     ranenv_create
  *   association.step / update_ues  associations/mult_slice.py:350-488   ranenv_load_scenarios,
  *                                                                       ranenv_set_episodes
- *   channel.step  (SE tile per TTI)     channels/quadriga.py:38-76      ranenv_bind_se_pool
+ *   channel.step  (SE tile per TTI)     channels/quadriga.py:38-76      ranenv_bind_se_pool, ranenv_bind_se_pool_quad
+ *                                                                       (+ ranenv_se_from_power, ranenv_se_retile_quad)
  *   traffic.step  (offered bits)        traffics/mult_slice.py:15-34    ranenv_bind_traffic_pool
  *   env.reset(seed, options)                        simu.py:547-554     ranenv_reset
  *   env.step(action):                               simu.py:559         ranenv_step
@@ -34,7 +35,8 @@
  *   - there is no CPU fallback: if no gfx950 device/kernel image is usable the calls fail.
  *   - sizes supported by this build: S <= 16, max_ues_slice <= 16, U <= 256, R <= 512,
  *     hist_depth <= 64; packet counts must stay below 2^31 (checked when scenarios are loaded).
- *   - SE tiles are RB-major: element (rb r, ue u) of a tile at offset r*U + u.
+ *   - SE tiles are RB-major: element (rb r, ue u) of a tile at offset r*U + u (the order of the reference's .mat); a POOL may also be
+ *     bound RB-quad-major, element at ((r/4)*U + u)*4 + r%4 (ranenv_bind_se_pool_quad: 16-byte loads, same results).
  */
 #ifndef RANENV_H
 #define RANENV_H
@@ -45,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RANENV_ABI_VERSION 8
+#define RANENV_ABI_VERSION 9
 
 enum {
     RANENV_OK = 0,

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranenv_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
 INTRA_RR, INTRA_PF, INTRA_MT, INTRA_PER_SLICE = 0, 1, 2, 255
 F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK = 0x1, 0x2, 0x4

@@ -31,7 +31,7 @@ def test_step_kernels_fit_the_register_budget_of_their_waves_per_simd(kernels):
     """512 VGPRs per SIMD lane: 5 waves -> 96 (allocation granule 8), 4 -> 128, 2 -> 256.  No AGPRs anywhere (no MFMA: the RB x SE
     accumulation is a masked row reduction)."""
     def budget(name):
-        if "persist_kernel_tiny" in name:
+        if "_tiny" in name:           # the whole-row builds (persistent and one-TTI): 2 waves per SIMD
             return 256
         if "packed" in name or "_small" in name:
             return 128
