@@ -67,8 +67,9 @@ enum { MODE_STEP = 0, MODE_DENSE = 1, MODE_RESET = 2 };
 struct Tables {  // scenario pool on the device, rows of [n_scenarios]
     int32_t *slice_i32;  // [NS][S][8] active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
     double  *slice_f64;  // [NS][S][2] priority, traffic
-    int32_t *param_i32;  // [NS][S][3][2] metric, op
-    double  *param_f64;  // [NS][S][3]
+    int32_t *param_i32;  // [NS][S][3][2] metric, op -- in the slice's own order (the head kernel), then the same BY METRIC (the step kernel):
+                         // [NS][S][3][2] declared?, op of metric m (a later parameter for the same metric has overwritten an earlier one)
+    double  *param_f64;  // [NS][S][3] value in the slice's own order, then [NS][S][3] value of metric m (1.0 where undeclared)
     int32_t *slice_ues;  // [NS][S][Us]
     int32_t *slot;       // [3][NS][S*16] slot_ue (UE id, -1 = empty slot), slot_mp, slot_pk (its max_pkts / pkt_size)
     int32_t *slice_usecase;                 // [NS][S] SchedColORAN: bit 0 eMBB, bit 1 URLLC
@@ -1246,9 +1247,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         const unsigned t4 = (unsigned)tid * 4u, t8 = (unsigned)tid * 8u;
         if (tid < S * 8) st_si0 = row_at<PACK>(TB_slice_i32(p), (size_t)sc * S * 32, t4);
         if (tid + LW < S * 8) st_si1 = row_at<PACK>(TB_slice_i32(p), (size_t)sc * S * 32, t4 + LW * 4u);
-        if (tid < S * 6) st_pi0 = row_at<PACK>(TB_param_i32(p), (size_t)sc * S * 24, t4);
-        if (tid + LW < S * 6) st_pi1 = row_at<PACK>(TB_param_i32(p), (size_t)sc * S * 24, t4 + LW * 4u);
-        if (tid < S * 3) st_pf = row_at<PACK>(TB_param_f64(p), (size_t)sc * S * 24, t8);
+        // (the intent parameters BY METRIC: the second block of the two tables, NS * S rows behind the first; NS * S = NSL / 16)
+        const size_t by_metric = (size_t)(p.NSL / GRP) * 24;
+        if (tid < S * 6) st_pi0 = row_at<PACK>(TB_param_i32(p), by_metric + (size_t)sc * S * 24, t4);
+        if (tid + LW < S * 6) st_pi1 = row_at<PACK>(TB_param_i32(p), by_metric + (size_t)sc * S * 24, t4 + LW * 4u);
+        if (tid < S * 3) st_pf = row_at<PACK>(TB_param_f64(p), by_metric + (size_t)sc * S * 24, t8);
         if (tid < S * 2) st_sf = row_at<PACK>(TB_slice_f64(p), (size_t)sc * S * 16, t8);
     }
     // device policy: this TTI's allocation may have been made at the end of the previous step
@@ -1521,28 +1524,20 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         // slice row for the drift, from the tables parked in LDS (read here, not at the top of the role: 17 registers
         // that would otherwise be alive through the buffer update)
         asm volatile("" ::: "memory");
-        int has_req = 0, bsize = 1, blat = 1, msg = 1, npar = 0;
-        int pm[3] = {0, 0, 0}, po[3] = {0, 0, 0};
-        double pv[3] = {0.0, 0.0, 0.0};
+        int has_req = 0, bsize = 1, blat = 1, msg = 1;
+        bool dec[3] = {false, false, false};
+        double val[3] = {1.0, 1.0, 1.0};
+        int opm[3] = {0, 0, 0};
         if (slc >= 0) {
             const int *si = sh.si[slc];
-            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5]; npar = si[6];
+            has_req = si[1]; bsize = si[3]; blat = si[4]; msg = si[5];
+            // (value, operator) of each metric: resolved on the host when the scenario was loaded (a later parameter for the same metric
+            // overwrites, :132-335), parked by metric
 #pragma unroll
-            for (int k = 0; k < 3; k++) { pm[k] = sh.pi[slc][2 * k]; po[k] = sh.pi[slc][2 * k + 1]; pv[k] = sh.pf[slc][k]; }
+            for (int m = 0; m < 3; m++) { dec[m] = sh.pi[slc][2 * m] != 0; opm[m] = sh.pi[slc][2 * m + 1]; val[m] = sh.pf[slc][m]; }
         }
         if (slc >= 0 && has_req) {
             const double o = COLD(over);
-            bool dec[3] = {false, false, false};
-            double val[3] = {1.0, 1.0, 1.0};
-            int opm[3] = {0, 0, 0};
-#pragma unroll
-            for (int qi = 0; qi < 3; qi++) {          // a later parameter for the same metric overwrites (:132-335)
-#pragma unroll
-                for (int m = 0; m < 3; m++) {
-                    const bool hit = qi < npar && pm[qi] == m;
-                    dec[m] = dec[m] || hit; val[m] = hit ? pv[qi] : val[m]; opm[m] = hit ? po[qi] : opm[m];
-                }
-            }
             // Each formula is "intent met ? a / b : -(c / d)" (plus a cap at 1 when over-fulfilled): one division
             // on the selected operands gives the bits of whichever arm is taken.
             if (dec[RANENV_METRIC_THROUGHPUT]) {
@@ -1651,7 +1646,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         s = sh.si[spos][7];
         const int *si = sh.si[s];
         active = si[0];
-        const int has_req = si[1], npar = si[6], n = si[2];
+        const int has_req = si[1], n = si[2];
         int rbs_s = 0;
 #pragma unroll
         for (int k = 0; k < NP; k++) rbs_s += sh.cnt[s][k];
@@ -1659,13 +1654,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         const double traffic_tab = sh.sf[s][1];
         if (n > 0 && has_req) {                                                    // common.py:343-378
 #pragma unroll
-            for (int qi = 0; qi < 3; qi++) {
-                if (qi < npar) {
-                    const int m = sh.pi[s][2 * qi];
-                    const double mean = m == 0 ? mean_row[0] : (m == 1 ? mean_row[1] : mean_row[2]);
-                    sv[0] = m == 0 ? mean : sv[0]; sv[1] = m == 1 ? mean : sv[1]; sv[2] = m == 2 ? mean : sv[2];
-                }
-            }
+            for (int m = 0; m < 3; m++) sv[m] = sh.pi[s][2 * m] != 0 ? mean_row[m] : sv[m];      // (declared metrics: the table is by metric)
         }
         const double traffic_req = active == 1 ? traffic_tab : 0.0;                // ib_sched.py:125-134
         const double priority = n != 0 ? priority_tab : 0.0;                       // :135-141
@@ -1724,15 +1713,13 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     auto wave_sync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     wave_sync();
     // ---- player_0 reward (common.py:409-427) ------------------------------------------------------
-    int n_neg = 0, n_prio_neg = 0;
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-        const double ao = xr[0][j], pr = xr[1][j];
-        n_neg += (j < S && ao < 0.0) ? 1 : 0;
-        n_prio_neg += (j < S && pr * ao < 0.0) ? 1 : 0;
-    }
-    const int mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
+    // (how many slices are in violation, all / priority ones: every slice lane holds its own entry -- two ballots instead of a loop over
+    // the LDS rows in every lane)
     const double my_ao = xr[0][tid], my_pr = xr[1][tid];
+    const unsigned row_sh = PACK == 2 ? (threadIdx.x & 32u) : 0u;
+    const int n_neg = __popc((unsigned)((__ballot(tid < S && my_ao < 0.0) >> row_sh) & 0xffffull));
+    const int n_prio_neg = __popc((unsigned)((__ballot(tid < S && my_pr * my_ao < 0.0) >> row_sh) & 0xffffull));
+    const int mode_sel = n_neg == 0 ? 0 : (n_prio_neg != 0 ? 1 : 2);
     // episode metrics: distance to fulfilment = sum of the negative slice drifts (entries beyond S are 0), all slices and
     // priority slices (priority is 0 or 1), as a fixed tree over the 16 lanes
     double dist = 0.0, prio_dist = 0.0;
@@ -3337,7 +3324,7 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     const size_t NSL = (size_t)S * GRP;
     kp.BU = (long long)(B * U); kp.NSU = (long long)(NS * U); kp.NSL = (long long)(NS * NSL);
     ALLOC(kp.tab.slice_i32, NS * S * 8); ALLOC(kp.tab.slice_f64, NS * S * 2);
-    ALLOC(kp.tab.param_i32, NS * S * 6); ALLOC(kp.tab.param_f64, NS * S * 3);
+    ALLOC(kp.tab.param_i32, 2 * NS * S * 6); ALLOC(kp.tab.param_f64, 2 * NS * S * 3);
     ALLOC(kp.tab.slice_ues, NS * S * Us); ALLOC(kp.tab.slice_usecase, NS * S);
     ALLOC(kp.tab.ue, (size_t)N_TUE * NS * U); ALLOC(kp.tab.slot, 3 * NS * NSL);
     ALLOC(kp.st.u4, (size_t)N_U4 * B * U); ALLOC(kp.st.u8, (size_t)N_U8 * B * U); ALLOC(kp.st.b4, (size_t)N_B4 * B);
@@ -3446,8 +3433,8 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t n = (size_t)count;
     // validate + pack on the host
-    std::vector<int32_t> si(n * S * 8), pi(n * S * 6);
-    std::vector<double> sf(n * S * 2), pf(n * S * 3);
+    std::vector<int32_t> si(n * S * 8), pi(n * S * 6), bmi(n * S * 6);
+    std::vector<double> sf(n * S * 2), pf(n * S * 3), bmf(n * S * 3);
     for (size_t i = 0; i < n * S; i++) {
         const int nues = t->slice_nues[i], npar = t->slice_nparams[i], srt = t->sorted_slices[i];
         if (nues < 0 || nues > Us) return fail(h, RANENV_E_INVALID, "slice_nues %d outside [0,%d]", nues, Us);
@@ -3463,6 +3450,12 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
             const int m = t->param_metric[i * 3 + k], op = t->param_op[i * 3 + k];
             if (k < npar && (m < 0 || m > 2 || op < 0 || op > 4)) return fail(h, RANENV_E_INVALID, "bad intent parameter (metric %d, op %d)", m, op);
             pi[(i * 3 + k) * 2] = m; pi[(i * 3 + k) * 2 + 1] = op; pf[i * 3 + k] = t->param_value[i * 3 + k];
+        }
+        // the same by metric, as intent_drift_calc walks the parameters (agents/common.py:132-335: a later one for the same metric wins)
+        for (int m = 0; m < 3; m++) { bmi[(i * 3 + m) * 2] = 0; bmi[(i * 3 + m) * 2 + 1] = 0; bmf[i * 3 + m] = 1.0; }
+        for (int k = 0; k < npar; k++) {
+            const int m = t->param_metric[i * 3 + k];
+            bmi[(i * 3 + m) * 2] = 1; bmi[(i * 3 + m) * 2 + 1] = t->param_op[i * 3 + k]; bmf[i * 3 + m] = t->param_value[i * 3 + k];
         }
         for (int k = 0; k < nues; k++) {
             const int ue = t->slice_ues[i * Us + k];
@@ -3522,6 +3515,8 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     PUT(d.slice_f64 + f * S * 2, sf.data(), n * S * 2, double);
     PUT(d.param_i32 + f * S * 6, pi.data(), n * S * 6, int32_t);
     PUT(d.param_f64 + f * S * 3, pf.data(), n * S * 3, double);
+    PUT(d.param_i32 + ((size_t)h->cfg.n_scenarios + f) * S * 6, bmi.data(), n * S * 6, int32_t);
+    PUT(d.param_f64 + ((size_t)h->cfg.n_scenarios + f) * S * 3, bmf.data(), n * S * 3, double);
     PUT(d.slice_ues + f * S * Us, t->slice_ues, n * S * Us, int32_t);
     PUT(TB_ue_slice(k) + f * U, lt[0].data(), n * U, int32_t);
     PUT(TB_ue_pos(k) + f * U, lt[1].data(), n * U, int32_t);
