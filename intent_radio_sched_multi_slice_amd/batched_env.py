@@ -177,6 +177,9 @@ class BatchedRanEnv:
                     st = self._lib.ranenv_se_retile_quad(_ptr(se_pool), _ptr(quad), se_pool.shape[0], self.U, self.R, self._stream())
                 if st != 0:
                     raise RanEnvError("ranenv_se_retile_quad failed: " + (self._lib.ranenv_last_error(None) or b"").decode())
+                # the copy is read by launches on other streams (partitions, ranges): a one-off build ends with a synchronisation, like
+                # the gather sidecars', instead of an event every such stream would have to wait for
+                torch.cuda.current_stream(self.device).synchronize()
         if quad is not None:
             self._keep["se_pool"] = quad
             self._check(self._lib.ranenv_bind_se_pool_quad(self._h, _ptr(quad), quad.shape[0], Rq * self.U * 4), "ranenv_bind_se_pool_quad")
