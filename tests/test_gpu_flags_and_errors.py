@@ -593,3 +593,43 @@ def test_the_very_first_step_of_a_handle_can_be_captured():
     assert int(outs[1][3].min()) == 5
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_graph_captured_step_with_device_autoreset_replays_through_episode_ends():
+    """A captured `env.step()` with auto-reset on holds the step, the advance kernel, the masked RESET launch and the sort of the class
+    lists -- the host's shortcut (nothing enqueued when its shadow of the step counters says no episode ended) must not apply inside a
+    capture, and the shadow ends there: replays through several episode ends equal eager steps, and eager steps behind the replays
+    carry on correctly."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    outs = []
+    for mode in ("eager", "graph"):
+        wl = make_mult_slice_workload(300, dev, n_scenarios=16, n_traces=8, trace_len=16, max_steps=1000)
+        env = wl.env
+        env.set_option("mix", 2); env.set_option("compact", 1)
+        n_ep, L = 10, wl.trace_len
+        ep = np.arange(n_ep)
+        env.set_episode_table(scenario=(ep * 3) % 16, se_base=(ep % 8) * L, se_len=L, se_offset=ep % L, trf_base=((ep * 3) % 16) * L, trf_len=L, trf_offset=(ep * 5) % L)
+        env.set_max_steps(4 + (np.arange(env.B) % 3))                  # episodes of 4, 5, 6 TTIs
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(env.B) % n_ep)
+        env.reset(); env.step(); torch.cuda.synchronize()
+        if mode == "eager":
+            for _ in range(17):
+                env.step()
+        else:
+            g = _captured_step_graph(env, dev)
+            for _ in range(14):
+                g.replay()
+            torch.cuda.synchronize()
+            for _ in range(3):                                          # eager again behind the replays
+                env.step()
+        torch.cuda.synchronize()
+        v = env.views()
+        outs.append((env.obs_inter.clone(), env.reward.clone(), env.done.clone(), v["queue_pkts"].clone(), v["step_number"].clone(),
+                     v["episode_number"].clone(), v["win_sent"].clone()))
+        env.close()
+    assert int(outs[0][5].max()) >= 3
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
