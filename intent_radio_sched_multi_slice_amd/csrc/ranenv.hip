@@ -422,6 +422,9 @@ DEVFN RowPlan make_row_plan(int n)
                                       per TTI) or 4 waves per SIMD without spills (31.7-32.3): the UE step gets slower, not faster -- that kernel is
                                       bound by VALU issue and LDS / barrier latency at full residency, not by these round trips (profiles/r05_ab_log.txt) */
 #endif
+#ifndef RANENV_SE_AUX
+#define RANENV_SE_AUX 2            /* cache policy bits of the tile loads (gfx94x: 1 = sc0, 2 = nt, 16 = sc1); 0 = the round-4 loads.  See nt_store */
+#endif
 #ifndef RANENV_SE_DEPTH_SMALL
 #define RANENV_SE_DEPTH_SMALL 4   /* the same for batches that do not fill the CUs anyway (step kernel built for 4 waves per SIMD) */
 #endif
@@ -447,8 +450,8 @@ struct SeStream {
         // padding of the last, partial group, never summed) are clamped to the last row instead (scalar min).
         if (quad) {
             const int s0 = (r0 >> 2) * row_bytes, s1 = s0 + row_bytes;
-            const se_v4f a = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 < last_row ? s0 : last_row, 0));
-            const se_v4f b = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s1 < last_row ? s1 : last_row, 0));
+            const se_v4f a = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 < last_row ? s0 : last_row, RANENV_SE_AUX));
+            const se_v4f b = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s1 < last_row ? s1 : last_row, RANENV_SE_AUX));
             dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
             return;
         }
@@ -456,7 +459,7 @@ struct SeStream {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int so = soff < last_row ? soff : last_row;
-            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, 0));
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, RANENV_SE_AUX));
             soff += row_bytes;
         }
     }
@@ -616,6 +619,9 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
 // Loads: two 16-byte buffer loads per group with the whole offset in the VGPR (range-checked: a lane that has no group
 // left gets an offset past the descriptor and reads 0 without touching memory), two groups in flight per lane.
 // ---------------------------------------------------------------------------------------------
+#ifndef RANENV_GATHER_AUX
+#define RANENV_GATHER_AUX 2        /* cache policy bits of the gather's loads from the UE-major copy (2 = nt: each is read once per TTI; 0 = plain) */
+#endif
 template <int PACK = 1, int DEPTH = 2>     // DEPTH: 8-RB groups in flight per lane (1: the packed one-TTI build, which has no register to spare)
 DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c)
 {
@@ -628,8 +634,8 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
     if constexpr (PACK == 1) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, tile_bytes, 0x00020000);
     auto ld8 = [&](float (&q)[8], int off) {
         if constexpr (PACK == 1) {
-            const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-            const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, 0));
+            const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, RANENV_GATHER_AUX));
+            const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, RANENV_GATHER_AUX));
             q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
         } else {
             v4f a = {0.0f, 0.0f, 0.0f, 0.0f}, b = a;
@@ -833,6 +839,26 @@ template <int PACK = 1, typename T> DEVFN T &row_at(T *array, size_t row_bytes, 
     } else {
         const unsigned off = (unsigned)row_bytes + lane_bytes;
         return *(T *)((char *)array + off);
+    }
+}
+
+// Cache hints (round 5; same-box A/B in profiles/r05_ab_log.txt).  The SE tile is read once per TTI and never again: its loads carry the
+// non-temporal bit, so that 292 MB of tiles per TTI do not push the per-UE state -- re-read at the very next TTI -- out of the caches
+// (streaming rollout -2...-3 %).  In the SE gather builds, which stream no tile, the same goes for what the kernel WRITES and will not read
+// again soon (observation rows, raw outputs, age-list and window-ring entries; gather -3.7 %; no gain for the streaming builds, so they
+// keep plain stores) and for the sidecar reads.
+#ifndef RANENV_NT_STORES
+#define RANENV_NT_STORES 1         /* 0: plain stores in the gather builds too */
+#endif
+template <bool NT, typename T> DEVFN void nt_store(T &dst, const T v)
+{
+    if constexpr (NT && RANENV_NT_STORES != 0) {
+        if constexpr (sizeof(T) == 8 && !std::is_floating_point<T>::value && !std::is_integral<T>::value)      // (int2: as one 8-byte word)
+            __builtin_nontemporal_store(__builtin_bit_cast(long long, v), (long long *)&dst);
+        else
+            __builtin_nontemporal_store(v, &dst);
+    } else {
+        dst = v;
     }
 }
 
@@ -1426,7 +1452,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             dropped += pkt_in - adm;
             if (adm > 0) {
                 int tail = head + nent; tail = tail >= L ? tail - L : tail;
-                row_at<PACK>(ring_env, 0, (unsigned)(tail * U + u) * 8u) = make_int2(t, adm);
+                nt_store<GATHER>(row_at<PACK>(ring_env, 0, (unsigned)(tail * U + u) * 8u), make_int2(t, adm));
                 if (nent == 0) { front = t; front_rem = adm; }
                 nent++;
                 total += adm;
@@ -1472,14 +1498,14 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         }
         // push into the 10-TTI window (IBSched.last_unformatted_obs.appendleft, ib_sched.py:64)
         win_sent += sent - old_s; win_drop += dropped - old_d;
-        *ring_s() = (int32_t)sent; *ring_d() = (int32_t)dropped;
+        nt_store<GATHER>(*ring_s(), (int32_t)sent); nt_store<GATHER>(*ring_d(), (int32_t)dropped);
         UE4(last_push) = ptot + 1;
         UE4(queue_pkts) = total; UE8(queue_age_sum) = sum_age;
         UE4(front) = front; UE4(front_rem) = front_rem; UE4(fifo) = fifo;
         UE8(win_sent) = win_sent; UE8(win_dropped) = win_drop;
         UE4(pkt_effective_thr) = (int32_t)sent; UE4(dropped_pkts) = (int32_t)dropped;
         if (!(COLD(flags) & RANENV_F_NO_RAW_OUTPUT)) {
-            UE4(pkt_incoming) = (int32_t)pkt_in; UE4(pkt_throughputs) = (int32_t)pkt_thr;
+            nt_store<GATHER>(UE4(pkt_incoming), (int32_t)pkt_in); nt_store<GATHER>(UE4(pkt_throughputs), (int32_t)pkt_thr);
         }
         sent_u = sent; drop_u = dropped;
 
@@ -1776,11 +1802,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (COLD(obs_inter)) {
             float *dst = COLD(obs_inter) + (size_t)e * S * 10;
-            for (int i = tid; i < S * 10; i += LW) row_at<PACK>(dst, 0, (unsigned)i * 4u) = sh.ob_inter[i];
+            for (int i = tid; i < S * 10; i += LW) nt_store<GATHER>(row_at<PACK>(dst, 0, (unsigned)i * 4u), sh.ob_inter[i]);
         }
         if (COLD(obs_intra)) {
             float *dst = COLD(obs_intra) + (size_t)e * S * W;
-            for (int i = tid; i < S * W; i += LW) row_at<PACK>(dst, 0, (unsigned)i * 4u) = sh.ob_intra[i];
+            for (int i = tid; i < S * W; i += LW) nt_store<GATHER>(row_at<PACK>(dst, 0, (unsigned)i * 4u), sh.ob_intra[i]);
         }
     }
 #endif
