@@ -425,6 +425,9 @@ DEVFN RowPlan make_row_plan(int n)
 #ifndef RANENV_SE_AUX
 #define RANENV_SE_AUX 2            /* cache policy bits of the tile loads (gfx94x: 1 = sc0, 2 = nt, 16 = sc1); 0 = the round-4 loads.  See nt_store */
 #endif
+#ifndef RANENV_SE_NT_LANE
+#define RANENV_SE_NT_LANE 1        /* the packed builds' tile loads (per-lane pointers) non-temporal as well */
+#endif
 #ifndef RANENV_SE_DEPTH_SMALL
 #define RANENV_SE_DEPTH_SMALL 4   /* the same for batches that do not fill the CUs anyway (step kernel built for 4 waves per SIMD) */
 #endif
@@ -444,14 +447,18 @@ struct SeStream {
     int voff, row_bytes;           // lane's byte offset inside a (quad-)row; bytes per (quad-)row
     bool quad;
     int last_row;                  // byte offset of the tile's last (quad-)row
+    // cache policy of the tile loads: non-temporal in the builds for big batches (queue of <= 2 groups), where the tiles would push the
+    // per-UE state out of the caches (see nt_store); plain in the deep-queue builds of small batches, which are latency-bound and lose
+    // 9 % with the hint (configs[1]: 18.9 -> 20.6 us per TTI)
+    static constexpr int AUX = SE_NQ <= 2 ? RANENV_SE_AUX : 0;
     DEVFN void load(float (&dst)[8], int r0)            // r0: a multiple of 8
     {
         // The scalar offset of a buffer load takes no part in the descriptor's range check: rows past the tile (the
         // padding of the last, partial group, never summed) are clamped to the last row instead (scalar min).
         if (quad) {
             const int s0 = (r0 >> 2) * row_bytes, s1 = s0 + row_bytes;
-            const se_v4f a = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 < last_row ? s0 : last_row, RANENV_SE_AUX));
-            const se_v4f b = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s1 < last_row ? s1 : last_row, RANENV_SE_AUX));
+            const se_v4f a = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s0 < last_row ? s0 : last_row, AUX));
+            const se_v4f b = __builtin_bit_cast(se_v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s1 < last_row ? s1 : last_row, AUX));
             dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
             return;
         }
@@ -459,7 +466,7 @@ struct SeStream {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int so = soff < last_row ? soff : last_row;
-            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, RANENV_SE_AUX));
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, so, AUX));
             soff += row_bytes;
         }
     }
@@ -497,7 +504,11 @@ struct SeStreamLane {
     {
         if (quad) {
             const int nq = (R + 3) >> 2, q0 = r0 >> 2, q1 = q0 + 1 < nq ? q0 + 1 : nq - 1;
+#if RANENV_SE_NT_LANE
+            const se_v4f a = __builtin_nontemporal_load((const se_v4f *)(col + (size_t)q0 * U * 4)), b = __builtin_nontemporal_load((const se_v4f *)(col + (size_t)q1 * U * 4));
+#else
             const se_v4f a = *(const se_v4f *)(col + (size_t)q0 * U * 4), b = *(const se_v4f *)(col + (size_t)q1 * U * 4);
+#endif
             dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
             return;
         }
