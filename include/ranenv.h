@@ -70,6 +70,14 @@ enum { RANENV_OP_GE = 0, RANENV_OP_LE = 1, RANENV_OP_EQ = 2, RANENV_OP_GT = 3, R
 #define RANENV_F_SYNC_CHECK             0x4 /* debug: reset / step / step_dense wait for their
                                                kernels and return RANENV_E_HIP on an asynchronous
                                                fault instead of leaving it to a later call     */
+#define RANENV_F_SCALE_PER_ELEMENT      0x8 /* default off.  How UEs.get_pkt_throughputs rounds (the env core sixg_radio_mgmt is absent
+                                               from the reference snapshot: parity unpinned).  Off:
+                                               floor(np.sum(sched * se) * (BW / R) / pkt_size) -- the sum is scaled.  On:
+                                               floor(np.sum(sched * se * (BW / R)) / pkt_size) -- every element is scaled (and rounded)
+                                               before it is added, in numpy's pairwise order either way.  The two differ by one packet
+                                               on rare inputs.  With the flag every step / dense launch runs the lean build compiled
+                                               for that convention: no mixed blocks, packed waves, small-batch / whole-row builds or
+                                               persistent launches (the options stay readable and have no effect).               */
 
 typedef struct ranenv *ranenv_handle;
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RANENV_LIB") or os.path.join(_HERE, "csrc", "libranen
 ABI_VERSION = 9
 POLICY_EXTERNAL, POLICY_MARR, POLICY_MAPF = 0, 1, 2
 INTRA_RR, INTRA_PF, INTRA_MT, INTRA_PER_SLICE = 0, 1, 2, 255
-F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK = 0x1, 0x2, 0x4
+F_CLEAR_HISTORY_ON_RESET, F_NO_RAW_OUTPUT, F_SYNC_CHECK, F_SCALE_PER_ELEMENT = 0x1, 0x2, 0x4, 0x8
 SE_STREAM, SE_GATHER = 0, 1
 
 EXPORTS = (

@@ -56,7 +56,8 @@
 
 namespace {
 
-enum { MODE_STEP = 0, MODE_DENSE = 1, MODE_RESET = 2 };
+enum { MODE_STEP = 0, MODE_DENSE = 1, MODE_RESET = 2,
+       MODE_PE = 4 };   // ORed into a step / dense build's MODE: RANENV_F_SCALE_PER_ELEMENT (the masked SE sum scales every element by BW / R before adding)
 
 // ---------------------------------------------------------------------------------------------
 // kernel parameters
@@ -537,8 +538,10 @@ struct SeStreamLane {
 // `after_issue` runs once, before the last turn of the queue (no load is requested in that turn): what the caller
 // loads there completes behind the tile (loads retire in order) while the last groups are being summed, and needs
 // no register during the rest of the stream.
-template <typename Src, typename InFn, typename Hook>
-DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook after_issue)
+// PE (RANENV_F_SCALE_PER_ELEMENT): `part` = sum of (sched * se) * scale with every product rounded on its own before it is added, as
+// np.sum(sched * se * (BW / R)) would; without it the caller scales the sum (-ffp-contract=off: the product below is not fused).
+template <bool PE = false, typename Src, typename InFn, typename Hook>
+DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook after_issue, const double scale = 1.0)
 {
     constexpr int SE_NQ = Src::NSLOT;
     const RowPlan pl = make_row_plan(R);
@@ -564,7 +567,7 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
             const double d = (double)x[j];
             f[j] += d;
 #if RANENV_DIAG != 11      /* ablation 11: the full sum alone (what a stream costs without the masked half) */
-            g[j] = fma(d, in(r0 + j) ? 1.0 : 0.0, g[j]);
+            g[j] = fma(PE ? d * scale : d, in(r0 + j) ? 1.0 : 0.0, g[j]);
 #endif
         }
         if (--left_in_leaf == 0) {
@@ -585,7 +588,7 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
             if (j < tail) {
                 const double d = (double)x[j];
                 fr += d;
-                gr = fma(d, in(r0 + j) ? 1.0 : 0.0, gr);
+                gr = fma(PE ? d * scale : d, in(r0 + j) ? 1.0 : 0.0, gr);
             }
         }
         fold(pl.n_leaves - 1);
@@ -633,8 +636,8 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
 #ifndef RANENV_GATHER_AUX
 #define RANENV_GATHER_AUX 2        /* cache policy bits of the gather's loads from the UE-major copy (2 = nt: each is read once per TTI; 0 = plain) */
 #endif
-template <int PACK = 1, int DEPTH = 2>     // DEPTH: 8-RB groups in flight per lane (1: the packed one-TTI build, which has no register to spare)
-DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c)
+template <int PACK = 1, int DEPTH = 2, bool PE = false>     // DEPTH: 8-RB groups in flight per lane (1: the packed one-TTI build, which has no register to spare)
+DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c, const double scale = 1.0)
 {
     constexpr int OOB = 0x7ffffff0;
     const RowPlan pl = make_row_plan(R);
@@ -677,7 +680,7 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
         for (int j = 0; j < 8; j++) g[j] = 0.0;
         auto consume = [&](const float (&x)[8], int r0) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) g[j] = fma((double)x[j], in(r0 + j) ? 1.0 : 0.0, g[j]);
+            for (int j = 0; j < 8; j++) g[j] = fma(PE ? (double)x[j] * scale : (double)x[j], in(r0 + j) ? 1.0 : 0.0, g[j]);
         };
         if constexpr (DEPTH == 2) {
 #pragma unroll 1
@@ -704,7 +707,7 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
                 ld8(q0, want_tail ? row_bytes_off + end * 4 : OOB);
 #pragma unroll
                 for (int j = 0; j < 7; j++)
-                    if (j < tail) gr = fma((double)q0[j], in(end + j) ? 1.0 : 0.0, gr);
+                    if (j < tail) gr = fma(PE ? (double)q0[j] * scale : (double)q0[j], in(end + j) ? 1.0 : 0.0, gr);
             }
         }
         const bool left = pl.lsplit ? (k < 2) : (k < 1);
@@ -1105,11 +1108,14 @@ struct StepCarry {
 #endif
 };
 
-template <int MODE, int NQ, bool GATHER, int NP, bool PERSIST = false, int PACK = 1, bool MIX = false, typename P>
+template <int MODE_X, int NQ, bool GATHER, int NP, bool PERSIST = false, int PACK = 1, bool MIX = false, typename P>
 DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,   // warm: `cy` holds what the previous TTI of this launch left
                      std::conditional_t<PACK == 2, SeStreamLane<GATHER ? 1 : NQ>, SeStream<GATHER ? 1 : NQ>> *se_carry = nullptr,
                      const bool se_ready = false, const bool se_next = false, const bool narrow_in = false)
 {                                     // -> true: this wave has left for good (nothing to do at later TTIs of the launch either)
+    constexpr int MODE = MODE_X & 3;
+    constexpr bool PE = (MODE_X & MODE_PE) != 0;
+    static_assert(!PE || (MODE != MODE_RESET && !PERSIST && PACK == 1 && !MIX), "per-element scaling: the lean step / dense builds");
     static_assert(!(GATHER && MODE == MODE_DENSE), "a dense sched_decision reads whole rows: streaming only");
     // PACK = 2 (envs of at most 32 UEs, one-wave workgroups): the wave steps TWO envs, lanes 0-31 the first, lanes 32-63 the second --
     // `tid` is the lane within the env's half, everything per env (index, counters, episode, tile, LDS image, row addresses) is a
@@ -1366,7 +1372,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 #if RANENV_GATHER_STATE_FIRST
         rest_of_state();          // requested ahead of the gather: both latencies run together
 #endif
-        if (MODE == MODE_STEP) my_part = gather_part<PACK, GDEPTH>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count);
+        if (MODE == MODE_STEP) my_part = gather_part<PACK, GDEPTH, PE>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count, PE ? COLD(bw_per_rb) : 1.0);
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
 #if RANENV_DIAG == 1 || RANENV_DIAG == 10
@@ -1374,11 +1380,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 #elif RANENV_DIAG == 2
         row_sums(se1, R, [=](int r) { return false; }, my_full, my_part, hook); my_part = (double)(us1 + uc1);
 #else
-        row_sums(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part, hook);
+        row_sums<PE>(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part, hook, PE ? COLD(bw_per_rb) : 1.0);
 #endif
     } else if constexpr (MODE == MODE_DENSE) {
         const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
-        row_sums(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part, hook);
+        row_sums<PE>(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part, hook, PE ? COLD(bw_per_rb) : 1.0);
     } else {
         row_sums(se1, R, [](int) { return false; }, my_full, my_part, hook);
     }
@@ -1432,7 +1438,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             const double psz = (double)pkt_size;
             // floor of non-negative values; v_cvt_i32_f64 truncates and saturates (host validates < 2^31)
             if (gen_traffic && !CARRY) traffic = draw_traffic();
-            pkt_thr = (int)ddiv(se_part * COLD(bw_per_rb), psz);
+            pkt_thr = (int)ddiv(PE ? se_part : se_part * COLD(bw_per_rb), psz);
             pkt_in = (int)ddiv(traffic, psz);
             const int L = p.L;
             // The queue is FIFO, so the age histogram Buffer keeps is exactly a list of (arrival TTI,
@@ -1854,9 +1860,10 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 // steps its env again as soon as it is done, from the state it has just written (its own CU's L1 / L2 hold it), instead
 // of ending and being launched again.  Between TTIs without a warm entry: every store of the workgroup is out and visible to
 // its other waves (full_sync: explicit vmcnt(0) + barrier; the waves of a workgroup share their CU's L1).
-template <int MODE, int NQ, bool GATHER, int NP, bool MANY, int PACK = 1, bool MIX = false>      // MANY: the build for launches of more than one TTI
+template <int MODE_X, int NQ, bool GATHER, int NP, bool MANY, int PACK = 1, bool MIX = false>      // MANY: the build for launches of more than one TTI
 DEVFN void step_loop(const KP &p)
 {
+    constexpr int MODE = MODE_X & 3;
     if constexpr (MODE == MODE_STEP) {
         // MIX: which env(s) this block steps comes from the class lists (ranenv_persist_classify_kernel): the first p_count blocks take one
         // env of the wide class each, the others two envs of the narrow class, one per wave
@@ -1882,7 +1889,7 @@ DEVFN void step_loop(const KP &p)
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
-            if (step_body<MODE, NQ, GATHER, NP, false, PACK, MIX>(*kc, cy, warm, MIX ? e_mix : kc->e0 + (int)blockIdx.x * PACK, nullptr, false, false, narrow)) return;
+            if (step_body<MODE_X, NQ, GATHER, NP, false, PACK, MIX>(*kc, cy, warm, MIX ? e_mix : kc->e0 + (int)blockIdx.x * PACK, nullptr, false, false, narrow)) return;
             if (k + 1 < n) {
                 // The next TTI takes over in registers what it would otherwise load back (StepCarry) -- unless it has to look
                 // for an allocation made ahead (RANENV_LATE) -- and then only LDS has to be handed over between the waves.
@@ -1892,7 +1899,7 @@ DEVFN void step_loop(const KP &p)
         }
     } else {
         StepCarry cy = {};
-        step_body<MODE, NQ, GATHER, NP>(p, cy, false, p.e0 + (int)blockIdx.x);
+        step_body<MODE_X, NQ, GATHER, NP>(p, cy, false, p.e0 + (int)blockIdx.x);
     }
 }
 #undef COLD
@@ -2186,7 +2193,7 @@ __global__ void __launch_bounds__(1024) ranenv_persist_classify_kernel(const ran
 template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
-    step_loop<MODE, (MODE == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP, MANY>(p);
+    step_loop<MODE, ((MODE & 3) == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP, MANY>(p);
 }
 #ifndef RANENV_SMALL_WAVES_PER_EU
 #define RANENV_SMALL_WAVES_PER_EU 4
@@ -2765,11 +2772,27 @@ int build_poisson_tables(ranenv_handle h, hipStream_t stream)
 }
 
 bool persist_tiny(ranenv_handle h);
+// RANENV_F_SCALE_PER_ELEMENT: every step / dense launch runs the lean build compiled for that convention -- no mixed blocks, packed
+// waves, small-batch / whole-row builds or persistent launches (those exist for the default convention only)
+bool scale_per_element(ranenv_handle h) { return (h->cfg.flags & RANENV_F_SCALE_PER_ELEMENT) != 0; }
 
 // The build of the step kernel for this handle: SE gather or streaming (lean / small-batch / whole-row), row width NP.
 template <int MODE, int NP, bool MANY>
 void launch_kernels_of(ranenv_handle h, const KP &kp, dim3 grid, dim3 block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, bool gather)
 {
+    // RANENV_F_SCALE_PER_ELEMENT: the lean builds with the other rounding of the masked SE sum (MODE_PE); a reset sums no masked row
+    if constexpr (MODE != MODE_RESET) {
+        if (scale_per_element(h)) {
+            if (gather) {
+                if constexpr (MODE == MODE_STEP) {
+                    if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE | MODE_PE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
+                    else hipLaunchKernelGGL((ranenv_core_kernel_gather<MODE | MODE_PE, NP, MANY>), grid, block, 0, stream, kp);
+                }
+            } else if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel<MODE | MODE_PE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
+            else hipLaunchKernelGGL((ranenv_core_kernel<MODE | MODE_PE, NP, MANY>), grid, block, 0, stream, kp);
+            return;
+        }
+    }
     if (gather) {
         if constexpr (MODE != MODE_DENSE) {
             if (ev0) hipExtLaunchKernelGGL((ranenv_core_kernel_gather<MODE, NP, MANY>), grid, block, 0, stream, ev0, ev1, 0, kp);
@@ -2833,7 +2856,7 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
     if constexpr (MODE == MODE_STEP) {
         // (whole-batch launches only: for the ranges of a partitioned batch per-range lists were built and measured -- two alternating
         // ranges 47.8 against 48.0 us per TTI in gather mode, and the streaming kernel loses the lane = UE order it wants there: dropped)
-        mixed = h->mix != 0 && kp.compact != 0 && h->nt == 2 * WAVE && e0 == 0 && n == h->cfg.batch && kp.env_mask == nullptr &&
+        mixed = !scale_per_element(h) && h->mix != 0 && kp.compact != 0 && h->nt == 2 * WAVE && e0 == 0 && n == h->cfg.batch && kp.env_mask == nullptr &&
                 (h->mix == 2 || !persist_tiny(h)) && RANENV_DIAG == 0;
         if (mixed && persist_prepare(h, stream, false) != RANENV_OK) return hipErrorUnknown;
     }
@@ -2877,7 +2900,7 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
             return hipGetLastError();
         }
         // packed waves: two envs per wave for envs of <= 32 UEs / <= 8 slices (see ranenv_core_kernel_packed)
-        if (h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr && pack_fits_32(h)) {
+        if (!scale_per_element(h) && h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr && pack_fits_32(h)) {
             KP kq = kp;
             kq.late = 0;
             const dim3 pgrid((unsigned)(n / 2)), pblock((unsigned)WAVE);
@@ -3325,6 +3348,8 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
         return fail(nullptr, RANENV_E_INVALID,
                     "unsupported sizes: need 1<=S<=16, 1<=U<=256, 1<=R<=512, 1<=Us<=16, 1<=G<=R, 1<=hist_depth<=64");
     if (!(cfg->bandwidth_hz > 0.0)) return fail(nullptr, RANENV_E_INVALID, "bandwidth_hz must be positive");
+    if (cfg->flags & ~(RANENV_F_CLEAR_HISTORY_ON_RESET | RANENV_F_NO_RAW_OUTPUT | RANENV_F_SYNC_CHECK | RANENV_F_SCALE_PER_ELEMENT))
+        return fail(nullptr, RANENV_E_INVALID, "unknown bits in flags (0x%x)", (unsigned)cfg->flags);
     if (!(cfg->norm_traffic > 0.0) || !(cfg->norm_ues > 0.0) || !(cfg->norm_se > 0.0))
         return fail(nullptr, RANENV_E_INVALID, "norm_traffic, norm_ues, norm_se (the observation's normalisers, agents/ib_sched.py:166-168) must be positive");
     if (R > 128) {   // the row reduction follows numpy's pairwise split two levels deep: every leaf must be <= 128 RBs
@@ -4024,7 +4049,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // (auto: not when episodes end at many different TTIs inside this call -- per-env episode lengths, envs reset at different times:
     // every episode end ends the persistent launches, re-sorts the envs and reads the class counts back; the launch-per-chunk
     // rollout follows the ends per partition without a host sync)
-    bool persist_ok = persist_wanted && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0 &&
+    bool persist_ok = persist_wanted && !scale_per_element(h) && kp.compact != 0 && !(kp.head_obs || kp.head_reward) && (h->cfg.batch >> PERSIST_ENV_BITS) == 0 &&
                       !stream_capturing(stream);      // (it reads the class counts back)
     if (persist_ok && h->persist < 0 && follow) {
         std::vector<int> ends;

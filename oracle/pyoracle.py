@@ -69,6 +69,8 @@ def lib():
             getattr(_lib, name).argtypes = [C.c_void_p]
             getattr(_lib, name).restype = None
         _lib.orc_env_set_scenario.argtypes = [C.c_void_p, C.POINTER(_Scenario)]
+        _lib.orc_env_set_scale_per_element.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_env_set_scale_per_element.restype = None
         _lib.orc_env_step_number.argtypes = [C.c_void_p]
         _lib.orc_env_hist_len.argtypes = [C.c_void_p]
     return _lib
@@ -182,6 +184,10 @@ class OracleEnv:
 
     def clear(self):
         lib().orc_env_clear(self._h)
+
+    def set_scale_per_element(self, on: bool):
+        """RANENV_F_SCALE_PER_ELEMENT's convention (include/ranenv.h): every sched * se element is scaled by BW / R before it is added."""
+        lib().orc_env_set_scale_per_element(self._h, 1 if on else 0)
 
     def set_scenario(self, tables, idx: int):
         """``tables``: any object with the ScenarioTables array attributes; row ``idx``."""

@@ -172,6 +172,7 @@ struct orc_env {
     int8_t *mask_intra;    /* S*Us */
     double *reward;        /* S+1 */
     double *scratch;       /* max(U, R, S) doubles x 4 */
+    int scale_per_element; /* orc_env_set_scale_per_element (include/ranenv.h RANENV_F_SCALE_PER_ELEMENT) */
 };
 
 static raw_rec *deque_at(const orc_env *e, int i)
@@ -230,6 +231,8 @@ void orc_env_destroy(orc_env *e)
     free(e->mask_intra); free(e->reward); free(e->scratch);
     free(e);
 }
+
+void orc_env_set_scale_per_element(orc_env *e, int on) { e->scale_per_element = on != 0; }
 
 void orc_env_clear(orc_env *e)
 {
@@ -625,14 +628,19 @@ void orc_env_core_step(orc_env *e, const uint8_t *dense, const float *se_tile, c
     raw_rec *rec = deque_appendleft(e);        /* filled below, then observed */
     double *row = e->scratch;
     for (int u = 0; u < U; u++) {
-        /* UEs.get_pkt_throughputs: floor(sum_r sched*SE * BW/R / pkt_size) */
+        /* UEs.get_pkt_throughputs: floor(sum_r sched*SE * BW/R / pkt_size) -- the sum is scaled (the build's normative choice);
+         * scale_per_element: floor(sum_r (sched*SE * BW/R) / pkt_size) -- every product is rounded before it is added, as
+         * np.sum(sched * se * (BW / R)) would */
         double cnt = 0.0;
         for (int r = 0; r < R; r++) {
             int on = dense[(size_t)u * R + r] != 0;
-            row[r] = on ? (double)se_tile[(size_t)u * R + r] : 0.0;
+            double v = (double)se_tile[(size_t)u * R + r];
+            if (e->scale_per_element) v = v * bw_per_rb;
+            row[r] = on ? v : 0.0;
             cnt += on;
         }
-        double bits = orc_np_sum(row, R, 1) * bw_per_rb;
+        double bits = orc_np_sum(row, R, 1);
+        if (!e->scale_per_element) bits = bits * bw_per_rb;
         double pkt_size = (double)sc->ue_pkt_size[u];
         int64_t pkt_thr = (int64_t)floor(bits / pkt_size);
         int64_t pkt_in = (int64_t)floor(traffic_bits[u] / pkt_size);   /* UEs.get_pkt_incoming */

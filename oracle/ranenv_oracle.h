@@ -102,6 +102,9 @@ orc_env *orc_env_create(const orc_cfg *cfg);
 void     orc_env_destroy(orc_env *e);
 /* Forget everything, including the IBSched deque (a fresh process). */
 void     orc_env_clear(orc_env *e);
+/* RANENV_F_SCALE_PER_ELEMENT's convention for UEs.get_pkt_throughputs (default off: the sum is scaled by BW / R; on: every
+ * element is scaled and rounded before it is added).  Survives orc_env_clear. */
+void     orc_env_set_scale_per_element(orc_env *e, int on);
 /* Install the scenario of the next episode (pointers must outlive its use). */
 void     orc_env_set_scenario(orc_env *e, const orc_scenario *sc);
 

@@ -160,3 +160,38 @@ def test_trace_exercises_the_interesting_regimes():
     assert (fx["reward"][:, 0] < 0).any()
     assert (fx["buffer_latencies"] > 0).any()
     assert (fx["pkt_effective_thr"] < fx["pkt_throughputs"]).any()
+
+
+def test_pkt_throughputs_two_roundings_against_numpy():
+    """UEs.get_pkt_throughputs is unpinned (the env core is absent from the reference snapshot): the oracle's default scales the
+    SUM by BW / R, RANENV_F_SCALE_PER_ELEMENT's convention scales every ELEMENT first.  Both against numpy itself, on random
+    masks / SE and on integer-valued SE, where they differ by a packet now and then (the named case: 54 RBs of SE 1.0 from RB 77,
+    512-bit packets: 78 125 against 78 124)."""
+    from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
+    S, U, R, G, Us = 5, 25, 135, 5, 5
+    tabs = generate_scaled_scenarios(2, seed=3, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=3, min_ues=2)
+    tabs.ue_pkt_size[:] = 512
+    bw = 100e6 / R
+    rng = np.random.default_rng(5)
+    differ = 0
+    for trial in range(40):
+        se = (rng.integers(1, 7, (U, R)) if trial % 2 else rng.uniform(0.1, 7.5, (U, R))).astype(np.float32)
+        dense = np.zeros((U, R), dtype=np.uint8)
+        for u in range(U):
+            s = int(rng.integers(0, R)); c = int(rng.integers(0, R - s + 1))
+            dense[u, s:s + c] = 1
+        if trial == 1:
+            se[0, :] = 1.0; dense[0, :] = 0; dense[0, 77:131] = 1
+        got = {}
+        for flagged in (False, True):
+            o = pyoracle.OracleEnv(pyoracle.make_cfg(S, U, R, G, Us))
+            o.set_scale_per_element(flagged); o.set_scenario(tabs, 0); o.reset(se)
+            o.core_step(dense, se, np.zeros(U))
+            got[flagged] = o.raw()["pkt_throughputs"]
+        row = dense.astype(np.float64) * se.astype(np.float64)
+        assert np.array_equal(got[False], np.floor(np.sum(row, axis=1) * bw / 512.0))
+        assert np.array_equal(got[True], np.floor(np.sum(row * bw, axis=1) / 512.0))
+        if trial == 1:
+            assert got[False][0] == 78125 and got[True][0] == 78124
+        differ += int(np.sum(got[False] != got[True]))
+    assert differ >= 1
