@@ -37,15 +37,18 @@ def _draw_case(k):
 
 
 @pytest.mark.parametrize("k", range(N_CASES))
-@pytest.mark.parametrize("build", ["lean", "small", "gather", "packed", "mixed"])
+@pytest.mark.parametrize("build", ["lean", "small", "gather", "packed", "mixed", "per-element", "per-element-gather"])
 def test_fuzz_case_vs_oracle(k, build, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("RANENV_SMALL_BATCH", "0" if build in ("lean", "packed", "mixed") else "1")
     monkeypatch.setenv("RANENV_PACK", "1" if build == "packed" else "0")      # (packed: two envs per wave where U <= 32 and S, Us <= 8)
     monkeypatch.setenv("RANENV_MIX", "2" if build == "mixed" else "0")        # (mixed blocks where 64 < U <= 128 and the step is compact)
-    if build == "gather":           # the SE gather mode: sidecars built at bind, tiles read through them
+    if build.endswith("gather"):    # the SE gather mode: sidecars built at bind, tiles read through them
         monkeypatch.setenv("RANENV_SE_MODE", "gather")
+    # "per-element": RANENV_F_SCALE_PER_ELEMENT -- the other rounding of pkt_throughputs, in the oracle and in builds of their own
+    flagged = build.startswith("per-element")
+    from intent_radio_sched_multi_slice_amd import _lib
     from intent_radio_sched_multi_slice_amd.batched_env import BatchedRanEnv
     from intent_radio_sched_multi_slice_amd.scenario import generate_scaled_scenarios
     from oracle import pyoracle
@@ -62,7 +65,7 @@ def test_fuzz_case_vs_oracle(k, build, monkeypatch):
     trf = np.concatenate([poisson_traffic_rows(tabs, int(scen[b]), rng, steps) for b in range(B)]) * c["load"]
     trf = np.floor(trf)
     env = BatchedRanEnv(batch=B, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=G, max_ues_slice=Us,
-                        n_scenarios=tabs.n_scenarios, max_steps=steps, hist_depth=D)
+                        n_scenarios=tabs.n_scenarios, max_steps=steps, hist_depth=D, flags=_lib.F_SCALE_PER_ELEMENT if flagged else 0)
     env.load_scenarios(tabs)
     env.bind_se_pool(torch.as_tensor(np.ascontiguousarray(np.swapaxes(se_pool, -1, -2)), device=env.device))
     env.bind_traffic_pool(torch.as_tensor(trf.astype(np.int32), device=env.device))
@@ -70,7 +73,7 @@ def test_fuzz_case_vs_oracle(k, build, monkeypatch):
     ocfg = pyoracle.make_cfg(S, U, R, G, Us, max_steps=steps, hist_depth=D)
     oenvs = []
     for b in range(B):
-        o = pyoracle.OracleEnv(ocfg); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
+        o = pyoracle.OracleEnv(ocfg); o.set_scale_per_element(flagged); o.set_scenario(tabs, int(scen[b])); o.reset(se_pool[b * steps]); oenvs.append(o)
     if c["how"] == "external":
         env.set_policy(0, 255)
     else:
