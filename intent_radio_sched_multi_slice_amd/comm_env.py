@@ -46,7 +46,8 @@ class MARLCommEnv:
                  agent_name: str = "agent", seed: int = 0, *, root_path: str = ".", initial_episode_number: int = 0,
                  simu_name: str = "mult_slice", save_hist: bool = False, max_episode_number: int = 1,
                  enable_random_episodes: bool = False, config: Optional[dict] = None,
-                 max_ues_slice: Optional[int] = None, device: Optional[torch.device] = None):
+                 max_ues_slice: Optional[int] = None, device: Optional[torch.device] = None, flags: int = 0):
+        # flags: include/ranenv.h RANENV_F_* (e.g. _lib.F_SCALE_PER_ELEMENT: the other candidate rounding of UEs.get_pkt_throughputs)
         cfg = dict(config if config is not None else DEFAULT_CONFIGS[config_name])
         ce = CommunicationEnv()
         ce.bandwidths = np.array(cfg["bandwidths"], dtype=float)
@@ -71,7 +72,7 @@ class MARLCommEnv:
         self.max_ues_slice = int(max_ues_slice if max_ues_slice is not None else max(1, U // S))
         self._dev = BatchedRanEnv(batch=1, n_slices=S, n_ues=U, n_rbs=R, rbs_per_rbg=1, max_ues_slice=self.max_ues_slice,
                                   n_scenarios=1, bandwidth_hz=float(ce.bandwidths[0]), max_steps=ce.max_number_steps,
-                                  max_age_cap=int(cfg.get("max_age_cap", MAX_AGE_CAP_DEFAULT)), device=device)
+                                  max_age_cap=int(cfg.get("max_age_cap", MAX_AGE_CAP_DEFAULT)), device=device, flags=int(flags))
         self._dev.set_episodes(scenario=0)
         self._tables = ScenarioTables.empty(1, S, U, self.max_ues_slice)
         self._loaded_version = None

@@ -42,10 +42,12 @@ class _RawAgent:
         return sched
 
 
+@pytest.mark.parametrize("per_element", [False, True])
 @pytest.mark.parametrize("config", ["plumbing", "mult_slice"])
-def test_facade_matches_oracle(config):
+def test_facade_matches_oracle(config, per_element):
+    """(per_element: the facade created with RANENV_F_SCALE_PER_ELEMENT against the oracle in that convention)"""
     _need_gpu()
-    from intent_radio_sched_multi_slice_amd import plugins
+    from intent_radio_sched_multi_slice_amd import _lib, plugins
     from intent_radio_sched_multi_slice_amd.comm_env import DEFAULT_CONFIGS, MARLCommEnv
     from intent_radio_sched_multi_slice_amd.scenario import ScenarioTables
     from oracle import pyoracle
@@ -68,7 +70,7 @@ def test_facade_matches_oracle(config):
         cfg = dict(DEFAULT_CONFIGS["mult_slice"], max_number_steps=30)
         Assoc, chan, traf, us = plugins.MultSliceAssociation, plugins.MimicQuadriga, plugins.MultSliceTraffic, 5
     env = MARLCommEnv(chan, traf, plugins.SimpleMobility, Assoc, "mult_slice", "raw", 10, config=cfg,
-                      max_episode_number=3, max_ues_slice=us)
+                      max_episode_number=3, max_ues_slice=us, flags=_lib.F_SCALE_PER_ELEMENT if per_element else 0)
     agent = _RawAgent(env)
     env.set_agent_functions(agent.obs_space_format, agent.action_format, agent.calculate_reward)
     ce = env.comm_env
@@ -76,6 +78,7 @@ def test_facade_matches_oracle(config):
     ocfg = pyoracle.make_cfg(S, U, R, 1, us, bandwidth_hz=float(ce.bandwidths[0]), max_age_cap=int(cfg.get("max_age_cap", 400)),
                              max_steps=ce.max_number_steps)
     orc = pyoracle.OracleEnv(ocfg)
+    orc.set_scale_per_element(per_element)
     for episode in range(2):
         obs, _ = env.reset(seed=10 + episode) if episode == 0 else env.reset()
         tabs = ScenarioTables.empty(1, S, U, us)
