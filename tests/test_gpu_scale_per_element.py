@@ -58,6 +58,8 @@ def test_flagged_device_vs_flagged_oracle(size, se_mode, monkeypatch):
     from oracle import pyoracle
     if se_mode == "gather":
         monkeypatch.setenv("RANENV_SE_MODE", "gather")
+    else:
+        monkeypatch.delenv("RANENV_SE_MODE", raising=False)       # (the suite may run under the knob: tools/round5_knobs.sh)
     if size == "ref":
         S, U, R, G, Us, B = 5, 25, 135, 5, 5, 12
         tabs = generate_scaled_scenarios(4, seed=3, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=3, min_ues=2)
@@ -137,6 +139,8 @@ def test_range_launches_where_the_conventions_disagree(se_mode, monkeypatch):
     from oracle import pyoracle
     if se_mode == "gather":
         monkeypatch.setenv("RANENV_SE_MODE", "gather")
+    else:
+        monkeypatch.delenv("RANENV_SE_MODE", raising=False)       # (the suite may run under the knob: tools/round5_knobs.sh)
     S, U, R, G, Us = 5, 25, 135, 1, 5
     tabs = generate_scaled_scenarios(12, seed=9, n_slices=S, n_ues=U, max_ues_slice=Us, min_slices=2, min_ues=1)
     tabs.ue_pkt_size[:] = 64
