@@ -2232,10 +2232,16 @@ __global__ void __launch_bounds__(2 * WAVE) RANENV_CORE_ATTR ranenv_core_kernel_
 // idle, and the chip holds as many waves as it holds; one wave steps TWO envs (lanes 0-31 / 32-63, step_body's PACK = 2): half as many
 // waves per env-step.  What is wave-uniform in the other builds is per-lane here (more registers: 4 waves per SIMD), so it is a build
 // of its own, for step launches of an even number of envs; reset and dense launches keep one env per wave (same state layout).
+#ifndef RANENV_PACK_NQ
+#define RANENV_PACK_NQ 2           /* 8-RB groups in flight per lane in the packed streaming builds */
+#endif
+#ifndef RANENV_PACK_WPE
+#define RANENV_PACK_WPE 4
+#endif
 template <int NP, bool MANY, bool GATHER>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_packed(const KP p)
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(RANENV_PACK_WPE, RANENV_PACK_WPE))) ranenv_core_kernel_packed(const KP p)
 {
-    step_loop<MODE_STEP, GATHER ? (MANY ? 1 : 0) : 2, GATHER, NP, MANY, 2>(p);        // (one-TTI gather build: gather depth 1, it has no register to spare)
+    step_loop<MODE_STEP, GATHER ? (MANY ? 1 : 0) : RANENV_PACK_NQ, GATHER, NP, MANY, 2>(p);        // (one-TTI gather build: gather depth 1, it has no register to spare)
 }
 
 // ---------------------------------------------------------------------------------------------

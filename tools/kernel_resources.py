@@ -84,7 +84,8 @@ def _reparse(notes: str):
 
 
 def main():
-    ks = kernel_resources()
+    paths = [a for a in sys.argv[1:] if not a.startswith("--")]          # another build of the library: tools/kernel_resources.py <lib.so>
+    ks = kernel_resources(paths[0]) if paths else kernel_resources()
     if "--json" in sys.argv:
         print(json.dumps(ks, indent=1))
         return
