@@ -292,3 +292,81 @@ def test_autoreset_enqueues_nothing_when_no_episode_ended_and_the_same_as_ever_w
     assert int(outs[0]["episode_number"].max()) >= 2
     assert launches[1] == 2 * steps                       # a step + a masked RESET launch every TTI
     assert launches[0] == steps + 4, launches             # a RESET launch only behind TTIs 9, 13, 18 and 26
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_autoreset_shadow_follows_random_call_sequences(seed):
+    """The host's copy of the step counters (what lets ranenv_autoreset enqueue nothing behind a TTI at which no episode ended) against the
+    device's own `done` flags over random sequences of everything that moves or invalidates the counters: whole-batch steps, ranges
+    stepped different numbers of TTIs (ranenv_step_part / ranenv_autoreset_part), rollouts (which follow the episode ends
+    themselves and hand the counters back), full resets, masked resets and new per-env episode lengths (after which the host
+    cannot know the counters until the next full reset or rollout).  Handle A uses the library as a trainer would; handle B hands
+    every auto-reset a COPY of `done`, which the host cannot follow, so the device decides.  Same state after every call."""
+    _need_gpu()
+    import ctypes as C
+    B, n_ep, n_ranges = 48, 12, 3
+    rng = np.random.default_rng(seed)
+    plan = []
+    for _ in range(110):
+        r = rng.random()
+        if r < 0.45: plan.append(("step",))
+        elif r < 0.70: plan.append(("range", int(rng.integers(0, n_ranges)), int(rng.integers(1, 4))))
+        elif r < 0.80: plan.append(("rollout", int(rng.integers(1, 9))))
+        elif r < 0.87: plan.append(("reset",))
+        elif r < 0.93: plan.append(("masked_reset", rng.integers(0, 2, B).astype(np.uint8)))
+        else: plan.append(("max_steps", rng.integers(3, 10, B).astype(np.int32)))
+    envs = []
+    for follow in (True, False):
+        wl = _small_workload(B, 7)
+        env, tabs = wl.env, wl.tables
+        ep = np.arange(n_ep)
+        env.set_episode_table(scenario=(ep * 5) % tabs.n_scenarios, se_base=(ep % 4) * wl.trace_len, se_len=wl.trace_len, se_offset=ep % wl.trace_len,
+                              trf_base=((ep * 5) % tabs.n_scenarios) * wl.trace_len, trf_len=wl.trace_len, trf_offset=(ep * 3) % wl.trace_len)
+        env.set_max_steps(np.where(np.arange(B) % 2 == 0, 5, 8).astype(np.int32))
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep)
+        env.set_ranges(n_ranges)
+        if not follow:
+            env._autoreset = False              # (handle B calls ranenv_autoreset / _part itself, with a copy of `done`)
+        env.reset()
+        env.profile_begin()
+        envs.append(env)
+
+    def outs(env):
+        return (C.c_void_p(env.obs_inter.data_ptr()), C.c_void_p(env.obs_intra.data_ptr()), C.c_void_p(env.term_obs_inter.data_ptr()),
+                C.c_void_p(env.term_obs_intra.data_ptr()), None, C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream))
+
+    for i, op in enumerate(plan):
+        for env, follow in zip(envs, (True, False)):
+            if op[0] == "step":
+                env.step()
+                if not follow:
+                    mine = env.done.clone()
+                    assert env._lib.ranenv_autoreset(env._h, C.c_void_p(mine.data_ptr()), *outs(env)) == 0
+            elif op[0] == "range":
+                for _ in range(op[2]):
+                    env.step_async(op[1])
+                    env.step_wait(op[1])
+                    if not follow:
+                        mine = env.done.clone()
+                        assert env._lib.ranenv_autoreset_part(env._h, op[1], C.c_void_p(mine.data_ptr()), *outs(env)) == 0
+                        env.step_wait(op[1])
+            elif op[0] == "rollout":
+                env._autoreset, keep = True, env._autoreset        # (a rollout with auto-reset follows the episode ends itself, on either handle)
+                env.rollout(op[1])
+                env._autoreset = keep
+            elif op[0] == "reset":
+                env.reset()
+            elif op[0] == "masked_reset":
+                env.reset(env_mask=op[1])
+            else:
+                env.set_max_steps(op[1])
+        torch.cuda.synchronize()
+        va, vb = envs[0].views(), envs[1].views()
+        for k in ("step_number", "episode_number", "queue_pkts", "win_sent"):
+            assert torch.equal(va[k], vb[k]), (seed, i, op[0], k)
+        assert torch.equal(envs[0].obs_inter, envs[1].obs_inter), (seed, i, op[0])
+    assert int(envs[0].views()["episode_number"].max()) >= 3
+    launches = [env.profile_end()["n_launches"] for env in envs]
+    assert launches[0] < launches[1] - 20, launches          # handle A really skipped the auto-reset launches where it could
+    for env in envs:
+        env.close()
