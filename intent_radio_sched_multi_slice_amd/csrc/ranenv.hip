@@ -737,12 +737,32 @@ DEVFN void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, uns
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Poisson draw by table inversion: u = 64 random bits, result = smallest k with u < cdf[k]; the guide table
-// (indexed by the top 6 bits of u) gives a k at or below the answer, so the walk is a step or two.
+// Poisson draw by table inversion: u = 64 random bits, result = smallest k with u < cdf[k] (255 at most); the guide table
+// (indexed by the top 6 bits of u) gives a k at or below the answer.  The walk from there looks at four entries per turn, requested
+// together: one memory round trip per turn instead of one per entry (a wave walks as long as its slowest lane, and every
+// round trip is 1-2 us of the UE step under load).
+#ifndef RANENV_POISSON_WINDOW
+#define RANENV_POISSON_WINDOW 8     /* 1: the plain walk, one entry per turn */
+#endif
 DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsigned long long u)
 {
     int k = guide[u >> 58];
+#if RANENV_POISSON_WINDOW <= 1
     while (k < 255 && cdf[k] <= u) k++;
+#else
+    constexpr int WIN = RANENV_POISSON_WINDOW;
+    for (;;) {
+        unsigned long long c[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; j++) c[j] = cdf[k + j < 255 ? k + j : 255];
+        int adv = 0;
+        bool on = true;
+#pragma unroll
+        for (int j = 0; j < WIN; j++) { on = on && k + j < 255 && c[j] <= u; adv += on ? 1 : 0; }
+        k += adv;
+        if (adv < WIN) break;
+    }
+#endif
     return k;
 }
 
