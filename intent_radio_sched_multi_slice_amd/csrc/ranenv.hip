@@ -4066,12 +4066,17 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    const bool persist_wanted = (RANENV_DIAG == 0 || RANENV_DIAG == 12) && (h->persist == 1 || (h->persist < 0 && ((h->se_mode == RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h))));
+    // (auto, streaming: rollouts of 16...64 TTIs of a batch the chip holds at once -- see below)
+    const bool stream_short = h->se_mode != RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 20ll * h->n_cus && n_steps >= 16 && n_steps <= 64;
+    const bool persist_wanted = (RANENV_DIAG == 0 || RANENV_DIAG == 12) && (h->persist == 1 || (h->persist < 0 && ((h->se_mode == RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h) || stream_short)));
     // (auto: where it was measured to win or tie -- profiles/r04_ab_log.txt.  Gather mode: B 1024 -4...-6 %, 2048 -1 %, 4096 -6 %, 8192 -2 % per
     // TTI; a batch of several times what the chip holds -- 16 384 one-wave envs at the reference's own size -- swaps at every chunk and
     // loses 7 %.  Streaming: -10 % at <= 2 waves per SIMD with the whole-row build; at B 4096 a tie: six same-box pairs against the
     // launches of <= 10 TTIs over three partitions, between -5 and +6 % for rollouts of 200 TTIs (mean +0.2 %) and between -1 and +4 % for
-    // rollouts of 20 (mean +0.6 %) -- the streaming kernel is bound by HBM either way -- so there it stays off unless asked for.)
+    // rollouts of 20 (mean +0.6 %) -- the streaming kernel is bound by HBM either way -- so there it stayed off unless asked for.
+    // Round 5, RB-quad-major pool + non-temporal tile loads: same-box pairs on five boxes (profiles/r05_ab_log.txt) give -0.5...-3 % for
+    // rollouts of 20 (mean -1.6 %), -5 % for 16, about -1 % for 40...100, a tie at 200 and +9 % for rollouts of 10 (the staggered first chunk is
+    // most of such a call); B 8192 loses 7 % (more workgroups than slots: every chunk swaps).  Hence: on for 16...64 TTIs at <= 20 envs per CU.)
     // (auto: not when episodes end at many different TTIs inside this call -- per-env episode lengths, envs reset at different times:
     // every episode end ends the persistent launches, re-sorts the envs and reads the class counts back; the launch-per-chunk
     // rollout follows the ends per partition without a host sync)

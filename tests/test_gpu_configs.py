@@ -330,7 +330,13 @@ def test_config2_headline_schedule_vs_oracle(se_mode):
         env.set_option(f"fuse_first{i}", 0)
     sample, members = _headline_sample(wl)
     assert len(sample) >= 32 and (members[sample] <= 64).sum() >= 12 and (members[sample] > 64).sum() >= 12
-    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[2]")
+
+    def schedule(k):
+        # the auto rule (include/ranenv.h, option persist = -1): the gather mode always runs persistent launches at this size, the
+        # streaming kernel for rollouts of 16...64 TTIs -- the driver's blocks of 20 -- and launch-per-chunk otherwise
+        if env.get_option("persist") == -1:
+            assert env.get_option("last_rollout_persistent") == (1 if se_mode == "gather" or 16 <= k <= 64 else 0), (se_mode, k)
+    _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[2]", after_call=schedule)
     env.close()
 
 
