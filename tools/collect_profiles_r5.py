@@ -53,4 +53,14 @@ if os.path.exists(kt20):          # what a 20-TTI block (the driver's --steps 20
     out = subprocess.run([sys.executable, "tools/block_timeline.py", kt20, "20"] + ([f"{steady:.3f}"] if steady else []), capture_output=True, text=True).stdout
     open("profiles/r05_block_timeline_k20.txt", "w").write("# tools/block_timeline.py on `rocprofv3 --kernel-trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "
                                                            "--no-single-stream --no-gather --no-other-configs`\n" + out)
+# the driver's command under rocprofv3 --kernel-trace --stats: this library's kernels + the bench line of that very run
+ks20 = os.path.join(src, "prof_stream_k20/p_kernel_stats.csv")
+if os.path.exists(ks20):
+    rows = open(ks20).read().splitlines()
+    open("profiles/r05_stream_k20_kernel_stats.csv", "w").write("\n".join([rows[0]] + [r for r in rows[1:] if "ranenv_" in r]) + "\n")
+log20 = os.path.join(src, "prof_stream_k20.log")
+if os.path.exists(log20):
+    for ln in open(log20):
+        if ln.startswith("{"):
+            json.dump(json.loads(ln), open("profiles/r05_stream_k20_profiled_bench_line.json", "w"), indent=1)
 print("profiles updated from", src, "->", sorted(lines))
