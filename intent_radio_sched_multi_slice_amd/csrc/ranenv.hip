@@ -741,6 +741,10 @@ DEVFN void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, uns
 // (indexed by the top 6 bits of u) gives a k at or below the answer.  The walk from there looks at four entries per turn, requested
 // together: one memory round trip per turn instead of one per entry (a wave walks as long as its slowest lane, and every
 // round trip is 1-2 us of the UE step under load).
+#ifndef RANENV_NARROW_PRIO
+#define RANENV_NARROW_PRIO 1        /* s_setprio of the one-wave class's waves inside the persistent launches (0: none): that class finishes a rollout
+                                       ~7 % behind the two-wave class; issuing first evens them out (gather: K = 20 -2.4 %, K = 200 -0.5 %; streaming: nothing) */
+#endif
 #ifndef RANENV_POISSON_WINDOW
 #define RANENV_POISSON_WINDOW 8     /* 1: the plain walk, one entry per turn */
 #endif
@@ -2144,6 +2148,10 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RA
 {
     (void)p;                                         // (read in place, like step_loop)
 #if RANENV_DIAG == 0 || RANENV_DIAG == 12            /* (the other diagnostic / ablation builds run the launch-per-chunk rollout only) */
+#if RANENV_NARROW_PRIO
+    // the one-wave class finishes a rollout after the two-wave class (its envs have half the loads in flight): its waves issue first
+    if (blockDim.x == WAVE) __builtin_amdgcn_s_setprio(RANENV_NARROW_PRIO);
+#endif
     persist_loop<GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP>();
 #endif
 }
