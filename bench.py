@@ -107,24 +107,66 @@ def rank_env():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def timed_steps(step_fn, n_steps: int, sync_fn, barrier_fn, max_over_ranks_fn):
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_cmd(n_gpus: int, argv, port: int):
+    """The child command of a plain `python bench.py --gpus N` (N > 1, no launcher environment): one rank per GPU under
+    torch.distributed.run on 127.0.0.1, the same arguments passed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus: int, argv, popen=None) -> int:
+    """Start the N ranks as a CHILD process (never exec: this must also work from a process that touched the GPU), relay
+    rank 0's JSON line(s) on stdout and everything else on stderr, return the child's exit code.  Called before any
+    torch.cuda / HIP call of this process.  `popen` is the test hook (tests/test_bench_logic.py)."""
+    import subprocess
+    cmd = self_launch_cmd(n_gpus, argv, free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n_gpus)))
+    print("bench.py: --gpus %d without a launcher environment: starting %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = (popen or subprocess.Popen)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in child.stdout:
+        t = ln.strip()
+        is_line = False
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                is_line = "metric" in json.loads(t)
+            except ValueError:
+                pass
+        (sys.stdout if is_line else sys.stderr).write(ln)
+        (sys.stdout if is_line else sys.stderr).flush()
+    return child.wait()
+
+
+def timed_steps(step_fn, n_steps: int, sync_fn, barrier_fn, max_over_ranks_fn, local_out=None):
     """EXACTLY n_steps calls of step_fn bracketed by barrier + device sync on both sides; wall-clock
-    seconds, MAX over ranks.  Shared with tests/test_bench_logic.py (gloo, stub env)."""
+    seconds, MAX over ranks.  Shared with tests/test_bench_logic.py (gloo, stub env).  `local_out` (a list) also
+    receives this rank's own time up to its device sync, before the closing barrier: the per-GPU figure."""
     sync_fn(); barrier_fn(); sync_fn()
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step_fn()
-    sync_fn(); barrier_fn(); sync_fn()
+    sync_fn()
+    if local_out is not None:
+        local_out.append(time.perf_counter() - t0)
+    barrier_fn(); sync_fn()
     return max_over_ranks_fn(time.perf_counter() - t0)
 
 
-def timed_blocks(block_fn, sync_fn, barrier_fn, max_over_ranks_fn, sample_s: float = SAMPLE_S, max_repeats: int = 64):
+def timed_blocks(block_fn, sync_fn, barrier_fn, max_over_ranks_fn, sample_s: float = SAMPLE_S, max_repeats: int = 64, local_out=None):
     """block_fn() enqueues EXACTLY the K steps of one block.  One block is timed (bracketed as in timed_steps), then the
     block is repeated max(1, ceil(sample_s / that time)) times, each repeat bracketed and timed on its own; returns the
     list of per-block times (every rank derives the same repeat count from the MAX-over-ranks time)."""
     first = timed_steps(block_fn, 1, sync_fn, barrier_fn, max_over_ranks_fn)
     repeats = max(1, min(max_repeats, int(math.ceil(sample_s / max(first, 1e-9)))))
-    return [timed_steps(block_fn, 1, sync_fn, barrier_fn, max_over_ranks_fn) for _ in range(repeats)]
+    return [timed_steps(block_fn, 1, sync_fn, barrier_fn, max_over_ranks_fn, local_out) for _ in range(repeats)]
 
 
 def block_stats(times, env_steps_per_block: float, steps: int):
@@ -306,6 +348,10 @@ def main():
                     help="plumbing rehearsal of a multi-rank launch on a box with ONE GPU: every rank uses cuda:0 and the process "
                          "group is gloo (RCCL refuses two ranks on one device); the line is labelled a rehearsal, not a measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the plain command: this process only starts the ranks (one per GPU) and relays rank 0's line; nothing here has
+        # touched torch.cuda / HIP yet
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     args.config_name = args.config
     args.config = 5 if args.config == "native" else int(args.config)
 
@@ -317,8 +363,7 @@ def main():
 
     world, rank, local_rank = rank_env()
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but the launcher started WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the env step has no CPU fallback")
     dev_index = 0 if args.rehearse_on_one_gpu else local_rank
@@ -368,11 +413,13 @@ def main():
         env.set_partitions(parts)
         env.reset()
         env.rollout(max(1, args.warmup))
-        times = timed_blocks(lambda: env.rollout(K), sync, barrier, max_over_ranks)
+        local = []
+        times = timed_blocks(lambda: env.rollout(K), sync, barrier, max_over_ranks, local_out=local)
         env.profile_begin()
         env.rollout(K)
         kms = env.profile_end()
         kms["persistent"] = bool(env.get_option("last_rollout_persistent"))     # (reported by the library, not inferred)
+        kms["local_block_s"] = float(np.median(local))                            # this rank's own median block, before the barrier
         return times, kms
 
     times = kms = None
@@ -382,6 +429,17 @@ def main():
         times, kms = rollout_variant()
         # metrics: the only collective, once per reporting interval, outside the timed K steps ...
         gathered = gm(local_metrics(env.reward, env.views(), env.done, K))
+        if world > 1:
+            # what the collective itself saw, and every GPU's own clock (its median block up to its own device sync)
+            alg_tti = env.algorithmic_bytes_per_env_step("stream") * batch
+            mine = torch.tensor([kms["local_block_s"]], dtype=torch.float64, device=device)
+            per_rank_s = gm(mine)[:, 0].tolist()
+            extras["ranks_seen"] = {"world_size": dist.get_world_size(), "all_gather_rows": int(gathered.shape[0]),
+                                    "backend": dist.get_backend()}
+            extras["per_gpu"] = {"median_block_s": per_rank_s,
+                                 "roofline_frac": [alg_tti * K / t / (HBM_PEAK_GBS * 1e9) for t in per_rank_s],
+                                 "note": "every rank's own median block of K steps up to its own device sync (before the closing "
+                                         "barrier), gathered with the metrics collective; roofline.frac above uses the MAX-over-ranks clock"}
         if world > 1:     # ... and one variant with it inside: K steps + the all_gather of the interval's accumulators
             tg = timed_blocks(lambda: (env.rollout(K), gm(local_metrics(env.reward, env.views(), env.done, K))),
                               sync, barrier, max_over_ranks)

@@ -88,3 +88,44 @@ def test_bench_rank_logic_world_size_2_gloo(tmp_path):
     m = line["metrics"]
     assert m["env_steps"] == B * K * world and m["pkts_sent"] == B * 5 * (1 + 2) and m["pkts_incoming"] == 2 * m["pkts_sent"]
     assert line["config"]["global_batch"] == B * world
+
+
+def test_plain_gpus_n_command_starts_its_own_ranks_and_relays_line_and_rc(monkeypatch, capsys):
+    """`python bench.py --gpus 2 ...` without a launcher environment: the child command is torch.distributed.run with one
+    rank per GPU on 127.0.0.1 and the same arguments; rank 0's JSON line goes to stdout, other output to stderr, the
+    child's exit code is returned.  The child is a stub: nothing here starts a rank or touches a GPU."""
+    import io
+    sys.path.insert(0, REPO)
+    import bench
+    seen = {}
+
+    class StubChild:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('some rank noise\n{"not": "the line"}\n{"metric": "env-steps/s", "value": 1.0, "n_gpus": 2}\n')
+
+        def wait(self):
+            return 7
+
+    argv = ["--gpus", "2", "--steps", "20", "--warmup", "5", "--rehearse-on-one-gpu"]
+    rc = bench.self_launch(2, argv, popen=StubChild)
+    out = capsys.readouterr()
+    assert rc == 7
+    assert out.out.strip() == '{"metric": "env-steps/s", "value": 1.0, "n_gpus": 2}'
+    assert "some rank noise" in out.err and '{"not": "the line"}' in out.err
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[k + 1:] == argv
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+    # main() takes that path only for N > 1 with no WORLD_SIZE, and before importing anything that could touch a GPU
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    called = {}
+    monkeypatch.setattr(bench, "self_launch", lambda n, a: called.setdefault("args", (n, a)) and 0 or 3)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 3 and called["args"] == (2, argv)
