@@ -87,7 +87,7 @@ def cpu_baseline(wl, sample_envs: int, sample_steps: int):
     tile_idx = np.stack([eps["se_base"][:n] + (eps["se_offset"][:n] + t % W) % L for t in range(sample_steps)])
     uniq, inv = np.unique(tile_idx, return_inverse=True)
     inv = inv.reshape(tile_idx.shape)
-    se_host = wl.se_pool[torch.as_tensor(uniq, device=env.device)].transpose(1, 2).contiguous().cpu().numpy()
+    se_host = env.pooled_tiles(torch.as_tensor(uniq, device=env.device)).transpose(1, 2).contiguous().cpu().numpy()
     trf_host = wl.traffic_pool.cpu().numpy().astype(np.float64)
     intra = np.full((n, S), wl.intra, dtype=np.int32)
     pyoracle.batch_reset(oenvs, se_host, inv[0], cores)
@@ -379,8 +379,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     try:
+        # (keep_rb_major=False: the RB-major tensor the generator wrote is dropped once its RB-quad-major copy is bound -- one copy of
+        # the pool in HBM, shared zero-copy with the other_configs blocks)
         wl, label = make_bench_workload(args.config, device, batch=args.batch, n_traces=args.traces,
-                                        trace_len=args.trace_len, rank=rank, traffic=args.traffic)
+                                        trace_len=args.trace_len, rank=rank, traffic=args.traffic, keep_rb_major=False)
     except (torch.OutOfMemoryError, _lib.RanEnvError) as e:       # the first run on a new box must not die on plumbing
         raise SystemExit(f"rank {rank}: building the workload failed ({e}).  The SE pool is traces x trace_len x 54 KB "
                          f"(= {args.traces * args.trace_len * 54e3 / 1e9:.1f} GB here, generated on the GPU in 110 MB bursts) plus "

@@ -2,7 +2,7 @@
  * ranenv.h -- C ABI of the MI355X-native batched RAN-slicing environment step.
  *
  * One handle = B independent environments resident in the HBM of one GPU.  The library
- * (libranenv_hip.so, built from intent_radio_sched_multi_slice_amd/csrc/ranenv.hip for
+ * (libranenv_hip.so, built from intent_radio_sched_multi_slice_amd/csrc/ranenv_*.{hip,hpp,cpp} for
  * gfx950) replaces, for the per-TTI hot path only, what the reference does in Python:
  *
  *   reference interface (lasseufpa/intent_radio_sched_multi_slice)      entry point here
@@ -379,11 +379,15 @@ int ranenv_set_max_steps(ranenv_handle h, const int32_t *host_max_steps, void *s
  *                             copied to the term_* buffers (each may be NULL), the next episode's descriptor
  *                             installed and CommunicationEnv.reset applied (obs_* receive the new episode's first
  *                             observation; the step's rewards and done flags are left as they are).  No host sync.
- *                             `done` is a function of the env's step counter alone (step >= its episode length) and the host
- *                             follows the counters from a reset of the whole batch on: when dev_done is the buffer the last
- *                             step wrote and no episode ended at that TTI, the call enqueues NOTHING (an RL loop calls it
- *                             behind every step).  Flags the host cannot follow -- another buffer, a caller's masked reset
- *                             before, a stream capture -- are left to the device as before. */
+ *                             Option "autoreset_shortcut" = 1 (default 0; opt-in): the caller promises that dev_done holds
+ *                             exactly what the last step wrote.  `done` is then a function of the env's step counter alone
+ *                             (step >= its episode length) and the host follows the counters from a reset of the whole batch
+ *                             on: when dev_done is the buffer the last step wrote and no episode ended at that TTI, the call
+ *                             enqueues NOTHING (an RL loop calls it behind every step).  What the host cannot follow --
+ *                             another buffer, a caller's masked reset before, a stream capture, ranenv_get_views (its views
+ *                             are writable, step_number included), a persistent launch that gave up -- ends the shadow until
+ *                             the next reset of the whole batch and is left to the device.  With the option at 0 the device
+ *                             always reads dev_done: a caller may OR its own truncation flags into the buffer. */
 int ranenv_set_episode_table(ranenv_handle h, const ranenv_episode *host_table, int32_t first_episode,
                              int32_t n_episodes, void *stream);
 int ranenv_set_autoreset(ranenv_handle h, int32_t enable, int32_t initial_episode, int32_t max_episode,
@@ -399,7 +403,7 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
 /* Options: tuning and debug knobs of the launch schedule.  NONE of them changes a result -- every setting is covered by the
  * bit-for-bit tests -- they select a build of the step kernel or the way launches are issued.  They are set per handle by
  * ranenv_set_option(h, key, value); ranenv_create presets them from the process environment, ONE variable per key,
- * RANENV_<KEY IN CAPITALS> (read in one place, apply_env_options in csrc/ranenv.hip; the GPU test suite and the A/B tools under
+ * RANENV_<KEY IN CAPITALS> (read in one place, apply_env_options in csrc/ranenv_host.cpp; the GPU test suite and the A/B tools under
  * tools/ run whole passes that way).  Nothing else in the library reads the environment.
  *
  *   key            env variable         default   meaning
@@ -439,6 +443,9 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *                                                 (host-visible memory, no device sync), clears the queues, sets "persist" to 0 for the handle and
  *                                                 fails with RANENV_E_STATE: the envs have advanced different numbers of TTIs, reset the batch
  *   "persist_inject_abort" (no env variable)      test hook: 1 = the next persistent launch finds a wait already given up
+ *   "autoreset_shortcut" RANENV_AUTORESET_SHORTCUT 0  1: ranenv_autoreset / _part trust the host's shadow of the step counters (see ranenv_autoreset) and
+ *                                                 enqueue nothing at a TTI at which no episode ended; 0: the device reads dev_done every time.
+ *                                                 (This one selects whose flags count -- with 1 the caller must not modify dev_done.)
  *   "last_rollout_persistent" / "last_rollout_launches" (read only)   what the last ranenv_rollout call ran: 1 = persistent work-queue
  *                                                 launches (else launches of <= 10 TTIs per partition); how many step-kernel launches it enqueued
  *   "persist_stat_keep" / "_push" / "_pop" / "_fresh" / "_idle_polls" (read only)   queue statistics of the persistent launches so far, summed over
@@ -450,6 +457,12 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  * ranenv_get_option reads a key back.  Unknown keys and unusable values return RANENV_E_INVALID. */
 int ranenv_set_option(ranenv_handle h, const char *key, int64_t value);
 int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value);
+
+/* Diagnostic, pure host arithmetic (no GPU, no handle): would a handle of this configuration with pools of these extents step two envs
+ * per wave (option "pack")?  Packed waves address a per-env row as array base + a 32-bit offset, so every array they address that way
+ * -- per-UE tables and state slabs, window rings, slice tables, the intent-parameter tables (two blocks), score / observation / reward
+ * rows, the traffic pool, the sidecar of per-tile means -- must stay below 4 GB.  1 = yes, 0 = no (one env per wave), < 0 = error. */
+int ranenv_packed_step_fits(const ranenv_config *cfg, int64_t traffic_rows, int64_t se_tiles);
 
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);

@@ -1,7 +1,7 @@
 """BatchedRanEnv: B independent RAN-slicing environments stepped by one HIP launch.
 
 Host side of the C ABI in include/ranenv.h.  PyTorch is plumbing here (device memory,
-streams); every number is produced by the gfx950 kernels in csrc/ranenv.hip.
+streams); every number is produced by the gfx950 kernels in csrc/ranenv_step_body.hpp (+ ranenv_aux.hip).
 
 gymnasium-style surface, batched (reference: ``env.reset`` / ``env.step`` simu.py:547-566):
 
@@ -150,13 +150,15 @@ class BatchedRanEnv:
         if first == 0 and tables.n_scenarios == self.n_scenarios:
             self.tables = tables
 
-    def bind_se_pool(self, se_pool: torch.Tensor, layout: Optional[str] = None):
+    def bind_se_pool(self, se_pool: torch.Tensor, layout: Optional[str] = None, keep_rb_major: bool = False):
         """float32 [n_tiles, R, U] (RB-major tiles, the order of the reference's .mat: channels/quadriga.py:70-72) resident on
-        this GPU.  ``layout``: how the library replays it -- ``"quad"`` (default; ``RANENV_SE_LAYOUT`` overrides): a copy in
-        RB-quad-major order [n_tiles, ceil(R/4), U, 4] is made once (ranenv_se_retile_quad, the same size again; the caller may
-        drop its RB-major tensor) and bound (ranenv_bind_se_pool_quad): 16-byte loads, a quarter of the memory instructions,
-        bit-identical results; ``"rb"``: the tensor itself is bound (ranenv_bind_se_pool).  A 4-D [n_tiles, ceil(R/4), U, 4]
-        tensor is taken as already re-tiled."""
+        this GPU.  ``layout``: how the library replays it -- ``"quad"`` (default; ``RANENV_SE_LAYOUT`` overrides): a COPY in
+        RB-quad-major order [n_tiles, ceil(R/4), U, 4] is made once (ranenv_se_retile_quad, the same size again) and bound
+        (ranenv_bind_se_pool_quad): 16-byte loads, a quarter of the memory instructions, bit-identical results.  The handle
+        then does NOT alias the caller's tensor: writes to ``se_pool`` after this call are not seen (bind again), and this
+        object keeps no reference to the RB-major tensor -- the caller may drop it and halve the pool's footprint -- unless
+        ``keep_rb_major`` (then it is kept in ``self.se_pool_rb_major``).  ``"rb"``: the tensor itself is bound, zero-copy
+        (ranenv_bind_se_pool).  A 4-D [n_tiles, ceil(R/4), U, 4] tensor is taken as already re-tiled (zero-copy)."""
         if se_pool.dtype != torch.float32 or se_pool.device != self.device or not se_pool.is_contiguous():
             raise RanEnvError("SE pool must be a contiguous float32 tensor on the env's GPU")
         Rq = (self.R + 3) // 4
@@ -180,6 +182,7 @@ class BatchedRanEnv:
                 # the copy is read by launches on other streams (partitions, ranges): a one-off build ends with a synchronisation, like
                 # the gather sidecars', instead of an event every such stream would have to wait for
                 torch.cuda.current_stream(self.device).synchronize()
+        self.se_pool_rb_major = se_pool if (keep_rb_major and se_pool.dim() == 3) else None
         if quad is not None:
             self._keep["se_pool"] = quad
             self._check(self._lib.ranenv_bind_se_pool_quad(self._h, _ptr(quad), quad.shape[0], Rq * self.U * 4), "ranenv_bind_se_pool_quad")
@@ -192,6 +195,11 @@ class BatchedRanEnv:
         self.se_mode = "stream"
         if os.environ.get("RANENV_SE_MODE") == "gather":       # experiment / test knob, like RANENV_SMALL_BATCH and RANENV_LATE
             self.set_se_mode("gather")
+
+    @property
+    def bound_se_pool(self) -> Optional[torch.Tensor]:
+        """The SE pool tensor the handle replays (RB-quad-major 4-D, or the caller's RB-major 3-D tensor under layout "rb")."""
+        return self._keep.get("se_pool")
 
     def pooled_tiles(self, tile_index: torch.Tensor) -> torch.Tensor:
         """Tiles of the bound pool as float32 [n, R, U] (RB-major, the reference's order) whatever layout is bound."""
@@ -321,11 +329,15 @@ class BatchedRanEnv:
         self.episode_table, self.episode_table_first = tab, int(first_episode)
 
     def enable_autoreset(self, initial_episode: int, max_episode: int, random_episodes: bool = False, seed: int = 0,
-                         episode_numbers=None):
+                         episode_numbers=None, shortcut: bool = True):
         """After every step, envs that reported ``done`` move to their next episode on the device (sequential, or
         random in [initial, max) like enable_random_episodes, simu.py:361,377) and are reset, without a host sync.
         ``episode_numbers`` [B]: the episode every env plays now (its descriptor is installed here).  The terminal
-        observation of those envs is kept in ``term_obs_inter`` / ``term_obs_intra`` (/ ``term_head_obs``)."""
+        observation of those envs is kept in ``term_obs_inter`` / ``term_obs_intra`` (/ ``term_head_obs``).
+        ``shortcut`` (library option ``autoreset_shortcut``): this class calls ranenv_autoreset right behind the step, inside
+        ``step()`` / ``step_async()``, with its own ``done`` buffer -- nobody can have touched the flags in between -- so the
+        library may follow the step counters on the host and enqueue nothing at a TTI at which no episode ended.  Pass
+        ``False`` if you write to ``views()["step_number"]`` (the views are cached here: the library cannot see later writes)."""
         ep = None
         if episode_numbers is not None:
             ep = np.ascontiguousarray(np.broadcast_to(np.asarray(episode_numbers, dtype=np.int32), (self.B,)))
@@ -340,6 +352,7 @@ class BatchedRanEnv:
                                                        1 if random_episodes else 0, int(seed) & (2 ** 64 - 1),
                                                        None if ep is None else C.c_void_p(ep.ctypes.data), self._stream()),
                         "ranenv_set_autoreset")
+        self.set_option("autoreset_shortcut", 1 if shortcut else 0)
         self.term_obs_inter = torch.zeros_like(self.obs_inter)
         self.term_obs_intra = torch.zeros_like(self.obs_intra)
         if getattr(self, "head_obs", None) is not None:

@@ -22,7 +22,7 @@ class Workload:
     name: str
     env: BatchedRanEnv
     tables: ScenarioTables
-    se_pool: torch.Tensor        # [tiles, R, U] float32
+    se_pool: torch.Tensor        # [tiles, R, U] float32 (RB-major); with keep_rb_major=False the pool as it is bound: RB-quad-major [tiles, ceil(R/4), U, 4]
     traffic_pool: torch.Tensor   # [rows, U] int32
     scenario: np.ndarray         # [B]
     se_trace: np.ndarray
@@ -52,8 +52,9 @@ def _se_pool_or(se_pool, n_traces, trace_len, n_ues, n_rbs, seed, device):
     """An SE pool of the wanted shape that is already resident (the same seed gives the same pool: bench.py hands the headline
     workload's pool to the other configs instead of generating 10.8 GB again), or a new one."""
     if se_pool is not None:
-        if tuple(se_pool.shape) != (n_traces * trace_len, n_rbs, n_ues) or se_pool.dtype != torch.float32 or se_pool.device != device:
-            raise ValueError("se_pool: float32 [n_traces * trace_len, R, U] on the env's device expected")
+        shapes = ((n_traces * trace_len, n_rbs, n_ues), (n_traces * trace_len, (n_rbs + 3) // 4, n_ues, 4))     # RB-major, or already RB-quad-major
+        if tuple(se_pool.shape) not in shapes or se_pool.dtype != torch.float32 or se_pool.device != device:
+            raise ValueError("se_pool: float32 [n_traces * trace_len, R, U] (or RB-quad-major [.., ceil(R/4), U, 4]) on the env's device expected")
         return se_pool
     return mimic_quadriga_pool(n_traces, trace_len, n_ues, n_rbs, seed, device)
 
@@ -102,7 +103,7 @@ def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POL
                              max_ues_slice: int = 10, max_steps: int = 1000, rank: int = 0,
                              name: Optional[str] = None, flags: int = 0, min_slices: Optional[int] = None,
                              min_ues: Optional[int] = None, se_pool: Optional[torch.Tensor] = None,
-                             se_layout: Optional[str] = None) -> Workload:
+                             se_layout: Optional[str] = None, keep_rb_major: bool = True) -> Workload:
     """BASELINE configs 2-4: S 10 / U 100 / R 135 allocation units, 6..10 active slices with
     distinct templates, 4..10 UEs per slice, MimicQuadriga-law SE replayed from HBM."""
     tables = generate_scaled_scenarios(n_scenarios, seed=seed, n_slices=n_slices, n_ues=n_ues,
@@ -116,6 +117,8 @@ def make_mult_slice_workload(batch: int, device: torch.device, policy: int = POL
     se_pool = _se_pool_or(se_pool, n_traces, trace_len, n_ues, n_rbs, seed + 1000 * (rank + 1), env.device)
     trf = torch.from_numpy(poisson_traffic_pool(tables, trace_len, seed + 7)).to(env.device)
     env.bind_se_pool(se_pool, layout=se_layout)
+    if not keep_rb_major:         # (the pool as bound -- one copy in HBM; env.pooled_tiles() still hands out RB-major tiles)
+        se_pool = env.bound_se_pool
     env.bind_traffic_pool(trf)
     rng = np.random.default_rng(seed + 31 * (rank + 1))
     scenario = rng.integers(0, n_scenarios, batch)
@@ -133,7 +136,8 @@ def make_mult_slice_seq_workload(batch: int, device: torch.device, policy: int =
                                  trace_len: int = 200, seed: int = 10, n_slices: int = 10, n_ues: int = 100,
                                  n_rbs: int = 135, rbs_per_rbg: int = 1, max_ues_slice: int = 10,
                                  max_steps: int = 1000, rank: int = 0, flags: int = 0,
-                                 se_pool: Optional[torch.Tensor] = None, se_layout: Optional[str] = None) -> Workload:
+                                 se_pool: Optional[torch.Tensor] = None, se_layout: Optional[str] = None,
+                                 keep_rb_major: bool = True) -> Workload:
     """BASELINE configs[4]: the ``mult_slice_seq`` per-scenario sweep.  Env e plays episode number
     ``rank*batch + e``; like MultSliceAssociationSeq / QuadrigaChannelSeq (associations/mult_slice_seq.py:38-46,
     channels/quadriga_seq.py:28-39) the association scenario is ``episode // channels_per_scenario`` (mod
@@ -150,6 +154,8 @@ def make_mult_slice_seq_workload(batch: int, device: torch.device, policy: int =
     se_pool = _se_pool_or(se_pool, n_traces, trace_len, n_ues, n_rbs, seed + 1000 * (rank + 1), env.device)
     trf = torch.from_numpy(poisson_traffic_pool(tables, trace_len, seed + 7)).to(env.device)
     env.bind_se_pool(se_pool, layout=se_layout)
+    if not keep_rb_major:         # (the pool as bound -- one copy in HBM; env.pooled_tiles() still hands out RB-major tiles)
+        se_pool = env.bound_se_pool
     env.bind_traffic_pool(trf)
     episode = np.arange(batch, dtype=np.int64) + rank * batch
     scenario = (episode // channels_per_scenario) % n_groups
@@ -164,28 +170,31 @@ def make_mult_slice_seq_workload(batch: int, device: torch.device, policy: int =
 
 
 def make_bench_workload(config: int, device: torch.device, batch: Optional[int] = None, n_traces: int = 200,
-                        trace_len: int = 200, rank: int = 0, traffic: str = "pool", se_pool: Optional[torch.Tensor] = None):
+                        trace_len: int = 200, rank: int = 0, traffic: str = "pool", se_pool: Optional[torch.Tensor] = None,
+                        keep_rb_major: bool = True):
     """The BASELINE.json ``configs[config]`` workload for one rank -> (Workload, label).  ``se_pool``: a resident pool of the
-    config's shape to bind instead of generating one (configs 1-4 share shape and seed: the same pool)."""
+    config's shape to bind instead of generating one (configs 1-4 share shape and seed: the same pool; RB-major or already
+    RB-quad-major, which is bound as it is).  ``keep_rb_major=False``: the generated RB-major tensor is dropped once the
+    RB-quad-major copy is bound (``wl.se_pool`` is then that copy)."""
     if config == 1:
         wl = make_mult_slice_workload(batch or 1024, device, policy=POLICY_MARR, intra=INTRA_RR, n_traces=n_traces,
-                                      trace_len=trace_len, rank=rank, se_pool=se_pool)
+                                      trace_len=trace_len, rank=rank, se_pool=se_pool, keep_rb_major=keep_rb_major)
         label = ("mult_slice, 10 slices, 100 UEs, 135 RBGs, MARR inter-slice + round-robin intra-slice + ib_sched "
                  "intent observation/reward")
     elif config in (2, 3):
         wl = make_mult_slice_workload(batch or 4096, device, policy=POLICY_MAPF, intra=INTRA_PF, n_traces=n_traces,
-                                      trace_len=trace_len, rank=rank, se_pool=se_pool)
+                                      trace_len=trace_len, rank=rank, se_pool=se_pool, keep_rb_major=keep_rb_major)
         label = ("mult_slice, 10 slices, 100 UEs, 135 RBGs, MAPF inter-slice + PF intra-slice + ib_sched intent "
                  "observation/reward")
     elif config == 4:
         wl = make_mult_slice_seq_workload(batch or 8192, device, policy=POLICY_MAPF, intra=INTRA_PF,
-                                          n_traces=n_traces, trace_len=trace_len, rank=rank, se_pool=se_pool)
+                                          n_traces=n_traces, trace_len=trace_len, rank=rank, se_pool=se_pool, keep_rb_major=keep_rb_major)
         label = ("mult_slice_seq per-scenario sweep, 10 scenario groups with 3..10 active slices (mixed masks and "
                  "intent metric sets), 100 UEs, 135 RBGs, MAPF + PF + ib_sched intent observation/reward")
     elif config == 5:       # not a BASELINE config: the size every reference agent is actually trained at
         wl = make_mult_slice_workload(batch or 16384, device, policy=POLICY_MAPF, intra=INTRA_PF, n_scenarios=200, n_traces=n_traces,
                                       trace_len=trace_len, rank=rank, n_slices=5, n_ues=25, n_rbs=135, rbs_per_rbg=5, max_ues_slice=5,
-                                      min_slices=3, min_ues=2, se_pool=se_pool)          # 3..5 active slices of 2..5 UEs (associations/mult_slice.py:359-423)
+                                      min_slices=3, min_ues=2, se_pool=se_pool, keep_rb_major=keep_rb_major)          # 3..5 active slices of 2..5 UEs (associations/mult_slice.py:359-423)
         label = ("reference-native size (env_config/mult_slice.yml:2-14, agents/ib_sched.py:50,56): 5 slices, 25 UEs, 27 RBGs of 5 "
                  "RBs, MAPF inter-slice + PF intra-slice + ib_sched intent observation/reward")
     else:

@@ -633,3 +633,113 @@ def test_graph_captured_step_with_device_autoreset_replays_through_episode_ends(
     assert int(outs[0][5].max()) >= 3
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def _autoreset_workload(dev, B=300, n_ep=12, L=16, flags=0):
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    wl = make_mult_slice_workload(B, dev, n_scenarios=16, n_traces=8, trace_len=L, max_steps=1000, flags=flags)
+    env = wl.env
+    ep = np.arange(n_ep)
+    env.set_episode_table(scenario=ep % 16, se_base=(ep % 8) * L, se_len=L, se_offset=ep % L, trf_base=(ep % 16) * L, trf_len=L,
+                          trf_offset=(ep * 3) % L)
+    env.set_max_steps(6 + (np.arange(B) % 4))
+    return wl, env, n_ep
+
+
+def test_autoreset_reads_the_callers_done_flags_unless_the_shortcut_was_opted_into():
+    """ranenv_autoreset's contract is "every env with dev_done != 0 restarts".  The host-shadow shortcut (nothing enqueued
+    when the host's copy of the step counters says no episode ended) is opt-in (option autoreset_shortcut, default 0): a caller that
+    ORs its own truncation flags into the buffer between the step and the call gets those envs restarted."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from intent_radio_sched_multi_slice_amd.batched_env import _ptr
+    dev = torch.device("cuda", 0)
+    wl, env, n_ep = _autoreset_workload(dev)
+    B = env.B
+    assert env.get_option("autoreset_shortcut") == 0                    # the library's default
+    env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep, shortcut=False)
+    assert env.get_option("autoreset_shortcut") == 0
+    env._autoreset = False                                              # this test calls ranenv_autoreset itself
+    env.reset()
+    for _ in range(3):
+        env.step()
+    torch.cuda.synchronize()
+    assert int(env.done.sum()) == 0                                     # no episode is over yet (lengths 6..9)
+    ep_before = env.views()["episode_number"].clone()
+    mine = torch.tensor([1, 7, 42, 299], device=dev)
+    env.done[mine] = 1                                                  # the caller's own truncation
+
+    def autoreset():
+        st = env._lib.ranenv_autoreset(env._h, _ptr(env.done), _ptr(env.obs_inter), _ptr(env.obs_intra), _ptr(env.term_obs_inter),
+                                       _ptr(env.term_obs_intra), None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert st == 0
+    autoreset()
+    torch.cuda.synchronize()
+    v = env.views()
+    restarted = torch.zeros(B, dtype=torch.bool, device=dev); restarted[mine] = True
+    assert torch.equal(v["step_number"][restarted], torch.zeros(4, dtype=torch.int32, device=dev))
+    assert torch.equal(v["step_number"][~restarted], torch.full((B - 4,), 3, dtype=torch.int32, device=dev))
+    assert bool((v["episode_number"][restarted] != ep_before[restarted]).all())
+    assert torch.equal(v["episode_number"][~restarted], ep_before[~restarted])
+    # opted in, the same call trusts the host's counters: flags the caller added are NOT looked at (documented)
+    env.reset()                                                         # (a reset of the whole batch restarts the shadow)
+    env.set_option("autoreset_shortcut", 1)
+    for _ in range(3):
+        env.step()
+    env.done[mine] = 1
+    autoreset()
+    torch.cuda.synchronize()
+    assert int(env.views()["step_number"].min()) == 3
+    env.close()
+
+
+def test_masked_reset_after_a_persistent_abort_does_not_leave_a_stale_step_shadow():
+    """persist_check_errors switched the persistent rollout off but left the host's shadow of the step counters
+    valid although the envs had advanced different numbers of TTIs.  A caller that answers the error with a MASKED reset (or none) and
+    carries on with env.step() + ranenv_autoreset (shortcut on) must get resets at the TTIs the DEVICE's counters say -- the same as a
+    handle that reached the same device state without the fault."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from intent_radio_sched_multi_slice_amd import _lib
+    dev = torch.device("cuda", 0)
+    wa, a, n_ep = _autoreset_workload(dev, flags=_lib.F_CLEAR_HISTORY_ON_RESET)
+    wb, b, _ = _autoreset_workload(dev, flags=_lib.F_CLEAR_HISTORY_ON_RESET)
+    B = a.B
+    for env in (a, b):
+        env.set_option("compact", 1)
+        env.set_max_steps(30 + (np.arange(B) % 4))                          # (no episode ends inside the broken rollout)
+        env.enable_autoreset(0, n_ep, episode_numbers=np.arange(B) % n_ep)  # shortcut on (the wrapper's default)
+    b.set_option("persist", 1); b.set_option("persist_grid", 128); b.set_option("persist_chunk", 2)
+    b.reset(); b.rollout(4); torch.cuda.synchronize()
+    assert b.get_option("last_rollout_persistent") == 1
+    b.set_option("persist_inject_abort", 1)
+    b.rollout(12); torch.cuda.synchronize()                                 # envs dropped after their first chunk: uneven step counters
+    with pytest.raises(_lib.RanEnvError, match="gave up"):
+        b.rollout(1)
+    steps_b = b.views()["step_number"].clone()
+    assert int(steps_b.min()) < int(steps_b.max())
+    # the caller's answer: reset only the envs that fell behind the most (a MASKED reset), keep the others where they are
+    mask = (steps_b == steps_b.min()).to(torch.uint8)
+    b.reset(env_mask=mask)
+    torch.cuda.synchronize()
+    steps_b = b.views()["step_number"].clone()
+    # handle a reaches the same device state honestly: full reset, then every env stepped to b's counter with a masked ... there is no
+    # masked step, so compare the BEHAVIOUR instead: from here on b must restart env e exactly when its device counter reaches its length
+    lens = torch.as_tensor(30 + (np.arange(B) % 4), device=dev, dtype=torch.int32)
+    ep0 = b.views()["episode_number"].clone()
+    n_resets = torch.zeros(B, dtype=torch.int32, device=dev)
+    cur = steps_b.clone()
+    for t in range(40):
+        b.step()
+        cur += 1
+        due = cur >= lens
+        torch.cuda.synchronize()
+        assert torch.equal(b.done.to(torch.bool), due), t                   # done as the device's counters say ...
+        cur[due] = 0
+        n_resets += due.to(torch.int32)
+        assert torch.equal(b.views()["step_number"], cur), t                # ... and those envs, only those, were restarted
+    assert int(n_resets.max()) >= 1 and int(n_resets.min()) >= 0
+    moved = b.views()["episode_number"] != ep0
+    assert torch.equal(moved, n_resets > 0) or n_ep == 1
+    a.close(); b.close()

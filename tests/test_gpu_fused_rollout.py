@@ -1,4 +1,4 @@
-"""ranenv_rollout's launches that take their envs through several TTIs (step_loop in csrc/ranenv.hip; include/ranenv.h
+"""ranenv_rollout's launches that take their envs through several TTIs (step_loop in csrc/ranenv_step_body.hpp; include/ranenv.h
 "ranenv_rollout"): bit for bit what one launch per TTI leaves behind -- state, observations, rewards, done flags, episode
 metrics -- with and without partitions, in both SE modes, across device auto-resets (launches end at the TTI at which an
 episode of the batch ends), with per-env episode lengths, with the traffic drawn on the device.  (Against the oracle the

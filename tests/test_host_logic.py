@@ -296,11 +296,14 @@ def test_create_rejects_unknown_flag_bits():
 
 def test_options_table_in_the_header_matches_the_library_and_the_environment_is_read_in_one_place():
     """VERDICT r3 hygiene: every knob of the launch schedule is an option documented in include/ranenv.h ("Options"); the keys
-    the library accepts are exactly the documented ones, and csrc/ranenv.hip reads the process environment in ONE function."""
+    the library accepts are exactly the documented ones, and the library's host side (csrc/ranenv_host.cpp) reads the process environment in ONE function; no other translation unit reads it at all."""
     import re
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(repo, "include", "ranenv.h")).read()
-    src = open(os.path.join(repo, "intent_radio_sched_multi_slice_amd", "csrc", "ranenv.hip")).read()
+    csrc = os.path.join(repo, "intent_radio_sched_multi_slice_amd", "csrc")
+    src = open(os.path.join(csrc, "ranenv_host.cpp")).read()
+    for other in ("ranenv_step.hip", "ranenv_step_body.hpp", "ranenv_numeric.hpp", "ranenv_aux.hip", "ranenv_internal.h"):
+        assert "getenv(" not in open(os.path.join(csrc, other)).read(), other
     table = hdr[hdr.index("/* Options:"):hdr.index("int ranenv_set_option")]
     documented = set(re.findall(r'^ \*\s+(?:\.\.\. )?"(\w+)"', table, flags=re.M))
     setter = src[src.index("int set_option(ranenv_handle h"):src.index("void apply_env_options")]
@@ -318,3 +321,33 @@ def test_options_table_in_the_header_matches_the_library_and_the_environment_is_
     for key in accepted - {"fuse_first0", "fuse_first9"}:
         assert f'"{key}"' in env_fn, key
         assert "RANENV_" + key.upper() in table, key
+
+
+def test_packed_waves_are_refused_where_a_32_bit_row_offset_could_wrap():
+    """packed waves (two envs per wave) address a per-env row as array base + a 32-bit offset; the guard must cover every
+    array addressed that way by its ACTUAL allocation -- the intent-parameter tables are two blocks of NS * S * 24 bytes, the per-UE
+    state slabs 13 / 4 fields of B * U elements, the score rows B * S * 8.  Pure host arithmetic (ranenv_packed_step_fits): no GPU."""
+    import ctypes as C
+    from intent_radio_sched_multi_slice_amd import _lib
+    lib = _lib.load()
+
+    def fits(B=16384, S=5, U=25, Us=5, NS=200, D=10, trf=200_000, tiles=200_000):
+        cfg = _lib.Config(_lib.ABI_VERSION, 0, B, S, U, 135, 5, Us, D, 400, 1000, NS, 0, 0, 100e6, 0.2, 120.0, 5.0, 40.0)
+        r = lib.ranenv_packed_step_fits(C.byref(cfg), trf, tiles)
+        assert r in (0, 1)
+        return bool(r)
+
+    lim = 1 << 32
+    assert fits()                                                # the reference's own size at the bench batch
+    # the by-metric block of the parameter tables: 2 * NS * S * 24 bytes (the round-5 guard checked NS * S * 32 only)
+    ns_edge = lim // (2 * 5 * 24)                                # 2 * ns_edge * 5 * 24 <= lim < 2 * (ns_edge + 1) * 5 * 24
+    assert 2 * ns_edge * 5 * 24 < lim or 2 * ns_edge * 5 * 24 == lim
+    assert not fits(NS=ns_edge + 1, U=1, Us=1)                   # (U = 1: the per-UE tables, 12 * NS * U * 4, stay below the bound)
+    assert fits(NS=ns_edge - 1, U=1, Us=1)
+    # the 4-byte state slab: 13 fields of B * U elements
+    b_edge = lim // (13 * 25 * 4)
+    assert not fits(B=b_edge + 1) and fits(B=b_edge - 2)
+    # the traffic pool and the sidecar of means
+    assert not fits(trf=lim // (25 * 4) + 1) and fits(trf=lim // (25 * 4) - 1)
+    assert not fits(tiles=lim // (25 * 8) + 1) and fits(tiles=lim // (25 * 8) - 1)
+    assert lib.ranenv_packed_step_fits(None, 0, 0) < 0

@@ -24,39 +24,44 @@ FIELDS = ("private_segment_fixed_size", "group_segment_fixed_size", "sgpr_count"
           "vgpr_spill_count", "agpr_count", "max_flat_workgroup_size")
 
 
-def code_object(so_path: str = SO) -> bytes:
-    """The gfx950 ELF inside the library's __CLANG_OFFLOAD_BUNDLE__."""
+def code_objects(so_path: str = SO):
+    """The gfx950 ELFs inside the library's __CLANG_OFFLOAD_BUNDLE__s (one bundle per linked object)."""
     so = open(so_path, "rb").read()
-    i = so.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    out, i = [], so.find(b"__CLANG_OFFLOAD_BUNDLE__")
     if i < 0:
         raise RuntimeError("no offload bundle in " + so_path)
-    (n,) = struct.unpack_from("<Q", so, i + 24)
-    p = i + 32
-    for _ in range(n):
-        off, size, tl = struct.unpack_from("<QQQ", so, p)
-        p += 24
-        triple = so[p:p + tl].decode()
-        p += tl
-        if "gfx950" in triple:
-            return so[i + off:i + off + size]
-    raise RuntimeError("no gfx950 image in " + so_path)
+    while i >= 0:
+        (n,) = struct.unpack_from("<Q", so, i + 24)
+        p = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", so, p)
+            p += 24
+            triple = so[p:p + tl].decode()
+            p += tl
+            if "gfx950" in triple and size > 0:
+                out.append(so[i + off:i + off + size])
+        i = so.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 24)
+    if not out:
+        raise RuntimeError("no gfx950 image in " + so_path)
+    return out
 
 
 def demangle(names):
     try:
         out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout
-        return [re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", x)).replace("(KP)", "") for x in out.split("\n")[:len(names)]]
+        return [re.sub(r"^void ", "", re.sub(r"\(anonymous namespace\)::", "", x)).replace("(ranenv_dev::KP)", "").replace("(KP)", "") for x in out.split("\n")[:len(names)]]
     except Exception:
         return list(names)
 
 
 def kernel_resources(so_path: str = SO):
-    co = code_object(so_path)
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(co)
-        f.flush()
-        notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", f.name], capture_output=True, text=True, check=True).stdout
-    kernels = _reparse(notes)
+    kernels = []
+    for co in code_objects(so_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            notes = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        kernels += _reparse(notes)
     for k, d in zip(kernels, demangle([k["mangled"] for k in kernels])):
         k["name"] = d
     return kernels
