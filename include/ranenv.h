@@ -412,8 +412,6 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *                                                 rollout (a quarter of n_steps, at most 10), n = at most n, 1 = one TTI per launch
  *   "fuse_first0"  RANENV_FUSE_FIRST    0         length of partition 0's FIRST launch of a rollout (0 = the staggered default:
  *   ... "fuse_first9"  (= a,b,c list)             the partition enqueued last starts with one TTI); keys 0..9 = partitions 0..9
- *   "late"         RANENV_LATE          0         1 / 2: a hashed half of / all envs under a device policy make the NEXT TTI's
- *                                                 allocation at the end of a step (the default while a launch was one TTI)
  *   "row_width"    RANENV_ROW_WIDTH     auto      8, 10 or 16 >= max(S, Us): LDS row width the step kernel is built for
  *   "small_batch"  RANENV_SMALL_BATCH   auto      1: the streaming build with 128 VGPRs and 32 SE loads in flight per lane (chosen
  *                                                 automatically when the batch leaves the CUs at <= 8 workgroups), 0: the lean one

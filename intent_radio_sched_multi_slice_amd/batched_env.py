@@ -193,7 +193,7 @@ class BatchedRanEnv:
                         "ranenv_bind_se_pool")
             self.se_layout = "rb"
         self.se_mode = "stream"
-        if os.environ.get("RANENV_SE_MODE") == "gather":       # experiment / test knob, like RANENV_SMALL_BATCH and RANENV_LATE
+        if os.environ.get("RANENV_SE_MODE") == "gather":       # experiment / test knob, like RANENV_SMALL_BATCH
             self.set_se_mode("gather")
 
     @property

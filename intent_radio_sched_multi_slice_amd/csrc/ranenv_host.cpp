@@ -27,7 +27,6 @@ struct ranenv {
     std::vector<void *> allocs;
     ranenv_episode *d_episodes = nullptr;
     bool have_scenarios = false, have_episodes = false;
-    int alloc_gen = 1;                          // bumped by everything a stored next-TTI allocation depends on
     ranenv_episode *d_ep_table = nullptr; int ep_table_first = 0, ep_table_n = 0;     // auto-reset: episode number -> descriptor
     int ar_initial = 0, ar_max = 0, ar_random = 0; unsigned long long ar_seed = 0; bool ar_on = false;
     uint8_t *d_ar_mask = nullptr;
@@ -275,7 +274,6 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         if (mixed) {
             const int B = h->cfg.batch;
             KP kq = kp;
-            kq.late = 0;
             kq.p_list = h->d_plist + (size_t)B; kq.m_list = h->d_plist; kq.m_counts = h->d_pcount;
             const dim3 mgrid((unsigned)n), mblock((unsigned)(2 * WAVE));       // (an upper bound of wide + ceil(narrow / 2))
             const StepLaunch l{h->np, SB_MIXED, MODE_STEP, kq.n_tti > 1, gather};
@@ -286,7 +284,6 @@ hipError_t launch_range(ranenv_handle h, KP kp, int e0, int n, hipStream_t strea
         // packed waves: two envs per wave for envs of <= 32 UEs / <= 8 slices (see ranenv_core_kernel_packed)
         if (!scale_per_element(h) && h->pack && h->np == 8 && h->cfg.n_ues <= 32 && h->nt == WAVE && (n & 1) == 0 && kp.env_mask == nullptr && pack_fits_32(h)) {
             KP kq = kp;
-            kq.late = 0;
             const dim3 pgrid((unsigned)(n / 2)), pblock((unsigned)WAVE);
             const StepLaunch l{8, SB_PACKED, MODE_STEP, kq.n_tti > 1, gather};
             (void)launch_step(l, pgrid, pblock, stream, ev0, ev1, kq);
@@ -381,16 +378,7 @@ hipError_t for_partitions(ranenv_handle h, hipStream_t stream, bool join_in, boo
     return hipSuccess;
 }
 
-// What every launch of a call shares: the host's allocation generation, and whether the next TTI's allocation may be made
-// ahead (role 0').  It may only when nothing a later call passes can change it: with the intra-slice scheduler taken from
-// the step's own intra_choice argument (RANENV_INTRA_PER_SLICE) an allocation made at the end of TTI t would use TTI t's
-// choices for TTI t+1, so there every step allocates at its head and no stored allocation is consumed.
-void finalize_kp(ranenv_handle h, KP &kp)
-{
-    kp.alloc_gen = h->alloc_gen;
-    kp.n_tti = 1;
-    if (kp.fixed_intra == RANENV_INTRA_PER_SLICE) kp.late = 0;
-}
+void finalize_kp(ranenv_handle, KP &kp) { kp.n_tti = 1; }      // (what every launch of a call shares: one TTI unless ranenv_rollout says more)
 
 template <int MODE>
 hipError_t launch(ranenv_handle h, KP kp, hipStream_t stream, bool join_in = true, bool join_out = true)
@@ -543,7 +531,7 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
 {
     const int B = h->cfg.batch, NC = h->p_nclass;
     const bool gather = h->se_mode == RANENV_SE_GATHER;
-    kp.n_tti = n_tti; kp.late = 0; kp.compact = 1; kp.e0 = 0;
+    kp.n_tti = n_tti; kp.compact = 1; kp.e0 = 0;
     kp.p_chunk = h->persist_chunk; kp.p_cap = h->p_cap; kp.p_err = h->d_perr_dev;
     if (gather) {
         kp.se_pool = h->d_se_um; kp.se_stride = (long long)h->cfg.n_ues * h->se_rp;
@@ -585,6 +573,10 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         KP kc = kp;
         // (every env of the class has a workgroup of its own and all of them are resident: nobody can ever be waiting, so the
         // launch is one chunk -- no looks at the queues, no staggered first chunk)
+        // (NOT for the other batches, although at B 4096 the grids equal the class sizes too -- 5119 of 5120 wave slots: two-wave blocks do not
+        // pack perfectly among one-wave blocks, a few dozen workgroups start late, and an env bound to one of those would wait for a whole
+        // rollout of somebody else; through the cursors the resident workgroups pick those envs up at their chunk ends.  Measured, round 6:
+        // block i <- list[i] costs +21 % per TTI at K = 20 and +27 % at K = 200 in gather mode, profiles/r06_ab_log.txt)
         if (tiny && g == n) kc.p_chunk = n_tti > 1 ? n_tti : 1;
         kc.p_list = h->d_plist + (size_t)c * B; kc.p_count = n; kc.p_ctl = h->d_pctl + c;
         kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
@@ -624,7 +616,6 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 {
     if (k == "compact") { h->compact_enabled = v != 0; return RANENV_OK; }
     if (k == "fuse") { h->fuse = v < 0 ? 0 : (v > 64 ? 64 : (int)v); return RANENV_OK; }
-    if (k == "late") { h->kp.late = v < 0 ? 0 : (v > 2 ? 2 : (int)v); h->alloc_gen++; return RANENV_OK; }
     if (k == "row_width") {
         const int m = h->cfg.n_slices > h->cfg.max_ues_slice ? h->cfg.n_slices : h->cfg.max_ues_slice;
         if (!((v == 8 || v == 10 || v == 16) && v >= m))
@@ -652,7 +643,7 @@ int set_option(ranenv_handle h, const std::string &k, long long v)
 
 void apply_env_options(ranenv_handle h)
 {
-    static const char *const keys[] = {"compact", "fuse", "late", "row_width", "small_batch", "tiny_step", "persist", "persist_chunk", "persist_grid", "pack", "mix", "autoreset_shortcut"};
+    static const char *const keys[] = {"compact", "fuse", "row_width", "small_batch", "tiny_step", "persist", "persist_chunk", "persist_grid", "pack", "mix", "autoreset_shortcut"};
     for (const char *key : keys) {
         std::string name = "RANENV_";
         for (const char *c = key; *c; c++) name += (char)toupper((unsigned char)*c);
@@ -719,7 +710,6 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     kp.B = cfg->batch; kp.S = S; kp.U = U; kp.R = R; kp.G = cfg->rbs_per_rbg; kp.Us = Us; kp.D = cfg->hist_depth;
     kp.L = (int)L; kp.max_steps = cfg->max_steps; kp.flags = cfg->flags; kp.T = R / cfg->rbs_per_rbg;
     kp.policy = RANENV_POLICY_MARR; kp.fixed_intra = RANENV_INTRA_RR;
-    kp.late = RANENV_LATE_DEFAULT;
     kp.bw_hz = cfg->bandwidth_hz; kp.bw_per_rb = cfg->bandwidth_hz / (double)R; kp.over = cfg->overfulfill;
     kp.norm_traffic = cfg->norm_traffic; kp.norm_ues = cfg->norm_ues; kp.norm_se = cfg->norm_se;
     int rc = RANENV_OK;
@@ -733,7 +723,6 @@ int ranenv_create(const ranenv_config *cfg, ranenv_handle *out)
     ALLOC(kp.st.u4, (size_t)N_U4 * B * U); ALLOC(kp.st.u8, (size_t)N_U8 * B * U); ALLOC(kp.st.b4, (size_t)N_B4 * B);
     ALLOC(kp.st.age_ring, B * L * U); ALLOC(kp.st.ring_sent, B * D * U); ALLOC(kp.st.ring_drop, B * D * U);
     ALLOC(kp.st.mask_inter, B * S); ALLOC(kp.st.mask_intra, B * S * Us); ALLOC(kp.st.policy_scores, B * S);
-    ALLOC(kp.st.next_scores, B * S);
     ALLOC(h->d_episodes, B); ALLOC(h->d_ar_mask, B); ALLOC(h->d_members, NS); ALLOC(h->d_cls_flag, 1);
 #undef ALLOC
     if (rc != RANENV_OK) { std::string m = h->err; ranenv_destroy(h); g_last_error = m; return rc; }
@@ -775,7 +764,6 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value)
     const std::string k(key);
     if (k == "compact") *value = h->compact_enabled ? 1 : 0;
     else if (k == "fuse") *value = h->fuse;
-    else if (k == "late") *value = h->kp.late;
     else if (k == "row_width") *value = h->np;
     else if (k == "small_batch") *value = h->small_batch ? 1 : 0;
     else if (k == "tiny_step") *value = h->tiny_step;
@@ -946,7 +934,7 @@ int ranenv_load_scenarios(ranenv_handle h, int32_t first, int32_t count, const r
     PUT(TB_slot_pk(k) + f * NSL, spk.data(), n * NSL, int32_t);
 #undef PUT
     HIP_TRY(h, hipStreamSynchronize(stream));  // staging vectors die at return
-    h->have_scenarios = true; h->alloc_gen++;
+    h->have_scenarios = true;
     if (h->slice_traffic.size() != NS_all(h)) { h->slice_traffic.assign(NS_all(h), 0.0); h->slice_has_req.assign(NS_all(h), 0); }
     for (size_t i = 0; i < n * S; i++) { h->slice_traffic[f * S + i] = t->slice_traffic[i]; h->slice_has_req[f * S + i] = t->slice_has_req[i]; }
     if (h->kp.trf_gen) { const int rc = build_poisson_tables(h, stream); if (rc != RANENV_OK) return rc; }
@@ -1024,7 +1012,7 @@ int ranenv_set_episodes(ranenv_handle h, const ranenv_episode *eps, void *stream
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(h, hipMemcpyAsync(h->d_episodes, eps, sizeof(ranenv_episode) * (size_t)h->cfg.batch, hipMemcpyHostToDevice, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
-    h->have_episodes = true; h->alloc_gen++; h->idle_check_dirty = true; h->pclass_dirty = true;
+    h->have_episodes = true; h->idle_check_dirty = true; h->pclass_dirty = true;
     return RANENV_OK;
 }
 
@@ -1034,7 +1022,7 @@ int ranenv_set_policy(ranenv_handle h, int32_t policy, int32_t fixed_intra)
     if (policy < RANENV_POLICY_EXTERNAL || policy > RANENV_POLICY_MAPF) return fail(h, RANENV_E_INVALID, "unknown policy %d", policy);
     if (!(fixed_intra == RANENV_INTRA_RR || fixed_intra == RANENV_INTRA_PF || fixed_intra == RANENV_INTRA_MT || fixed_intra == RANENV_INTRA_PER_SLICE))
         return fail(h, RANENV_E_INVALID, "unknown intra-slice scheduler %d", fixed_intra);
-    h->kp.policy = policy; h->kp.fixed_intra = fixed_intra; h->alloc_gen++;
+    h->kp.policy = policy; h->kp.fixed_intra = fixed_intra;
     return RANENV_OK;
 }
 

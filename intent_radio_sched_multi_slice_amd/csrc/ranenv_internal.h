@@ -17,10 +17,6 @@
                            9 / 12 stamp s_memtime at the phase boundaries of the one-TTI / the persistent launches (tools/stamps.py, persist_phases.py) */
 #endif
 
-#ifndef RANENV_LATE_DEFAULT
-#define RANENV_LATE_DEFAULT 0
-#endif
-
 namespace ranenv_dev {
 
 enum { MODE_STEP = 0, MODE_DENSE = 1, MODE_RESET = 2,
@@ -48,15 +44,13 @@ struct Tables {  // scenario pool on the device, rows of [n_scenarios]
 };
 
 struct State {
-    int32_t *u4;         // [13][B][U] 4-byte per-UE fields (the ST_* accessors below name them)
+    int32_t *u4;         // [11][B][U] 4-byte per-UE fields (the ST_* accessors below name them)
     int64_t *u8;         // [4][B][U]  8-byte per-UE fields: queue_age_sum, win_sent, win_dropped (int64), se_mean (double)
-    int32_t *b4;         // [10][B]    per-env counters
+    int32_t *b4;         // [9][B]     per-env counters
     int2 *age_ring; int32_t *ring_sent; int32_t *ring_drop;
     int8_t *mask_inter, *mask_intra; double *policy_scores;
-    double *next_scores; // with next_rb_start / next_rb_count: the allocation made at the end of a step for the next one
-                         // (device policy), valid while alloc_gen[e] == KP::alloc_gen
 };
-enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 12 };
+enum { N_U4 = 11, N_U8 = 4, N_B4 = 9, N_TUE = 12 };
 #define ST_queue_pkts(p) ((p).st.u4 + (size_t)(0) * (size_t)(p).BU)
 #define ST_front(p) ((p).st.u4 + (size_t)(1) * (size_t)(p).BU)
 #define ST_front_rem(p) ((p).st.u4 + (size_t)(2) * (size_t)(p).BU)
@@ -67,9 +61,7 @@ enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 12 };
 #define ST_dropped_pkts(p) ((p).st.u4 + (size_t)(7) * (size_t)(p).BU)
 #define ST_rb_start(p) ((p).st.u4 + (size_t)(8) * (size_t)(p).BU)
 #define ST_rb_count(p) ((p).st.u4 + (size_t)(9) * (size_t)(p).BU)
-#define ST_next_rb_start(p) ((p).st.u4 + (size_t)(10) * (size_t)(p).BU)
-#define ST_next_rb_count(p) ((p).st.u4 + (size_t)(11) * (size_t)(p).BU)
-#define ST_last_push(p) ((p).st.u4 + (size_t)(12) * (size_t)(p).BU)
+#define ST_last_push(p) ((p).st.u4 + (size_t)(10) * (size_t)(p).BU)
 #define ST_queue_age_sum(p) ((int64_t *)((p).st.u8 + (size_t)(0) * (size_t)(p).BU))
 #define ST_win_sent(p) ((int64_t *)((p).st.u8 + (size_t)(1) * (size_t)(p).BU))
 #define ST_win_dropped(p) ((int64_t *)((p).st.u8 + (size_t)(2) * (size_t)(p).BU))
@@ -79,18 +71,16 @@ enum { N_U4 = 13, N_U8 = 4, N_B4 = 10, N_TUE = 12 };
 #define ST_step_no(p) ((p).st.b4 + (size_t)(2) * (size_t)(p).B)
 #define ST_se_pos(p) ((p).st.b4 + (size_t)(3) * (size_t)(p).B)
 #define ST_trf_pos(p) ((p).st.b4 + (size_t)(4) * (size_t)(p).B)
-#define ST_alloc_gen(p) ((p).st.b4 + (size_t)(5) * (size_t)(p).B)
-#define ST_episode_no(p) ((p).st.b4 + (size_t)(6) * (size_t)(p).B)
-#define ST_reset_count(p) ((p).st.b4 + (size_t)(7) * (size_t)(p).B)
-#define ST_push_total(p) ((p).st.b4 + (size_t)(8) * (size_t)(p).B)
-#define ST_clear_mark(p) ((p).st.b4 + (size_t)(9) * (size_t)(p).B)
+#define ST_episode_no(p) ((p).st.b4 + (size_t)(5) * (size_t)(p).B)
+#define ST_reset_count(p) ((p).st.b4 + (size_t)(6) * (size_t)(p).B)
+#define ST_push_total(p) ((p).st.b4 + (size_t)(7) * (size_t)(p).B)
+#define ST_clear_mark(p) ((p).st.b4 + (size_t)(8) * (size_t)(p).B)
 #define ST_age_ring(p) ((p).st.age_ring)
 #define ST_ring_sent(p) ((p).st.ring_sent)
 #define ST_ring_drop(p) ((p).st.ring_drop)
 #define ST_mask_inter(p) ((p).st.mask_inter)
 #define ST_mask_intra(p) ((p).st.mask_intra)
 #define ST_policy_scores(p) ((p).st.policy_scores)
-#define ST_next_scores(p) ((p).st.next_scores)
 #define TB_ue_slice(p) ((p).tab.ue + (size_t)(0) * (size_t)(p).NSU)
 #define TB_ue_pos(p) ((p).tab.ue + (size_t)(1) * (size_t)(p).NSU)
 #define TB_ue_pkt_size(p) ((p).tab.ue + (size_t)(2) * (size_t)(p).NSU)
@@ -123,12 +113,8 @@ struct KP {
     int T;    // R / G: allocation units of the inter-slice split (an integer division costs a wave ~60 instructions: made once, on the host)
     int e0;   // first env of this launch
     int n_tti;       // TTIs this launch steps every env through (>= 1; more than one only inside ranenv_rollout)
-    int alloc_gen;   // host generation of (policy, scenarios, episodes): a stored next-TTI allocation of another generation is stale
     int compact;     // step only the UEs that are in a slice (lanes are ordered slice members first): waves without one leave
                      // at once.  Set by the host when it is exact: UEs outside every slice get no traffic (see idle_traffic_ok)
-    int late;        // 0 (default): every step allocates at its head; 1: a hashed half of the envs, 2: all envs allocate for the
-                     // next TTI at the end of the step (device policy only), so that heads and tails of workgroups differ in
-                     // what they load the CU with (RANENV_LATE; the default while a launch was one TTI)
     double bw_hz, bw_per_rb, over, norm_traffic, norm_ues, norm_se;
     Tables tab;
     State st;

@@ -201,53 +201,16 @@ DEVFN RowPlan make_row_plan(int n)
     return pl;
 }
 
-#ifndef RANENV_SE_DEPTH
-#define RANENV_SE_DEPTH 2          /* 8-row groups of the SE tile in flight per lane in the lean streaming kernel (step / reset at row
-                                      widths 8 and 10: 96 VGPRs without spills; the dense-mask and 16-wide builds keep 1) */
+// 8-row groups of the SE tile in flight per lane: the lean streaming kernel (step / reset at row widths 8 and 10: 96 VGPRs without spills;
+// the dense-mask and 16-wide builds keep 1), the build for batches that do not fill the CUs anyway (4 waves per SIMD), and the whole-row
+// builds of a batch at <= 2 waves per SIMD (R = 135: 16 groups of 8 + the tail group -- no load is requested inside the stream phase)
+constexpr int SE_DEPTH_LEAN = 2, SE_DEPTH_SMALL = 4, SE_DEPTH_TINY = 17, SE_DEPTH_PACKED = 2;
+#ifndef RANENV_CACHE_HINTS
+#define RANENV_CACHE_HINTS 1       /* 0: plain loads and stores everywhere (A/B of the hints only).  1: the tile loads of the big-batch streaming builds and
+                                      the gather builds' loads from the UE-major copy carry the non-temporal bit (gfx94x cache policy bits: 1 = sc0, 2 = nt,
+                                      16 = sc1), and the gather builds store what is not read again soon non-temporally (see nt_store) */
 #endif
-#ifndef RANENV_DEFER_STATE
-#define RANENV_DEFER_STATE 2   /* the part of the UE state the allocation does not need is requested 0: at kernel entry, 1: before
-                                  the queue's last turn, 2: after the stream (default: ~20 registers fewer while the tile
-                                  streams; with 8 loads in flight per lane the kernel fits 96 VGPRs = 5 waves per SIMD
-                                  without spills; measured A/B in profiles/r02_ab_log.txt) */
-#endif
-#ifndef RANENV_GATHER_STATE_FIRST
-#define RANENV_GATHER_STATE_FIRST 0
-#endif
-#ifndef RANENV_OBS_STAGE
-#define RANENV_OBS_STAGE 1
-#endif
-#ifndef RANENV_COLD_ARGS
-#define RANENV_COLD_ARGS 1
-#endif
-#ifndef RANENV_METRICS
-#define RANENV_METRICS 1           /* 0 compiles the episode-metric sums out (A/B of their cost only) */
-#endif
-#ifndef RANENV_WARM_ENTRY
-#define RANENV_WARM_ENTRY 1        /* 0: every TTI of a multi-TTI launch enters like the first (loads everything back) */
-#endif
-#ifndef RANENV_LATE_BUILT
-#define RANENV_LATE_BUILT 1        /* 0 compiles the allocation-ahead path out */
-#endif
-#ifndef RANENV_LATE_DEFAULT
-#define RANENV_LATE_DEFAULT 0      /* (1 until launches ran several TTIs: their workgroups drift apart by themselves, and allocating
-                                      ahead only costs its round trip through HBM -- rollout 62.1 -> 61.2, gather 37.8 -> 36.6 us per TTI) */
-#endif
-#ifndef RANENV_GATHER_CARRY
-#define RANENV_GATHER_CARRY 0      /* 1: the persistent SE gather build too carries the UE state between the TTIs of a chunk and requests the next TTI's
-                                      inputs ahead (CARRY).  Measured and left off: +15 registers = 21 spills at 5 waves per SIMD (33.3 against 31.2 us
-                                      per TTI) or 4 waves per SIMD without spills (31.7-32.3): the UE step gets slower, not faster -- that kernel is
-                                      bound by VALU issue and LDS / barrier latency at full residency, not by these round trips (profiles/r05_ab_log.txt) */
-#endif
-#ifndef RANENV_SE_AUX
-#define RANENV_SE_AUX 2            /* cache policy bits of the tile loads (gfx94x: 1 = sc0, 2 = nt, 16 = sc1); 0 = the round-4 loads.  See nt_store */
-#endif
-#ifndef RANENV_SE_NT_LANE
-#define RANENV_SE_NT_LANE 1        /* the packed builds' tile loads (per-lane pointers) non-temporal as well */
-#endif
-#ifndef RANENV_SE_DEPTH_SMALL
-#define RANENV_SE_DEPTH_SMALL 4   /* the same for batches that do not fill the CUs anyway (step kernel built for 4 waves per SIMD) */
-#endif
+constexpr int SE_AUX_NT = RANENV_CACHE_HINTS ? 2 : 0;
 
 // Two tile layouts (ranenv_bind_se_pool / ranenv_bind_se_pool_quad), a wave-uniform flag of the launch:
 //   RB-major       [R][U]        one dword per RB and lane: 8 load instructions per group of 8 RBs
@@ -267,7 +230,7 @@ struct SeStream {
     // cache policy of the tile loads: non-temporal in the builds for big batches (queue of <= 2 groups), where the tiles would push the
     // per-UE state out of the caches (see nt_store); plain in the deep-queue builds of small batches, which are latency-bound and lose
     // 9 % with the hint (configs[1]: 18.9 -> 20.6 us per TTI)
-    static constexpr int AUX = SE_NQ <= 2 ? RANENV_SE_AUX : 0;
+    static constexpr int AUX = SE_NQ <= 2 ? SE_AUX_NT : 0;
     DEVFN void load(float (&dst)[8], int r0)            // r0: a multiple of 8
     {
         // The scalar offset of a buffer load takes no part in the descriptor's range check: rows past the tile (the
@@ -321,7 +284,7 @@ struct SeStreamLane {
     {
         if (quad) {
             const int nq = (R + 3) >> 2, q0 = r0 >> 2, q1 = q0 + 1 < nq ? q0 + 1 : nq - 1;
-#if RANENV_SE_NT_LANE
+#if RANENV_CACHE_HINTS
             const se_v4f a = __builtin_nontemporal_load((const se_v4f *)(col + (size_t)q0 * U * 4)), b = __builtin_nontemporal_load((const se_v4f *)(col + (size_t)q1 * U * 4));
 #else
             const se_v4f a = *(const se_v4f *)(col + (size_t)q0 * U * 4), b = *(const se_v4f *)(col + (size_t)q1 * U * 4);
@@ -449,9 +412,6 @@ DEVFN void row_sums(Src &st, int R, InFn in, double &full, double &part, Hook af
 // Loads: two 16-byte buffer loads per group with the whole offset in the VGPR (range-checked: a lane that has no group
 // left gets an offset past the descriptor and reads 0 without touching memory), two groups in flight per lane.
 // ---------------------------------------------------------------------------------------------
-#ifndef RANENV_GATHER_AUX
-#define RANENV_GATHER_AUX 2        /* cache policy bits of the gather's loads from the UE-major copy (2 = nt: each is read once per TTI; 0 = plain) */
-#endif
 template <int PACK = 1, int DEPTH = 2, bool PE = false>     // DEPTH: 8-RB groups in flight per lane (1: the packed one-TTI build, which has no register to spare)
 DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c, const double scale = 1.0)
 {
@@ -464,8 +424,8 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
     if constexpr (PACK == 1) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, tile_bytes, 0x00020000);
     auto ld8 = [&](float (&q)[8], int off) {
         if constexpr (PACK == 1) {
-            const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, RANENV_GATHER_AUX));
-            const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, RANENV_GATHER_AUX));
+            const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SE_AUX_NT));
+            const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off < OOB ? off + 16 : OOB, 0, SE_AUX_NT));
             q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
         } else {
             v4f a = {0.0f, 0.0f, 0.0f, 0.0f}, b = a;
@@ -554,23 +514,13 @@ DEVFN void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, uns
 }
 
 // Poisson draw by table inversion: u = 64 random bits, result = smallest k with u < cdf[k] (255 at most); the guide table
-// (indexed by the top 6 bits of u) gives a k at or below the answer.  The walk from there looks at four entries per turn, requested
+// (indexed by the top 6 bits of u) gives a k at or below the answer.  The walk from there looks at eight entries per turn, requested
 // together: one memory round trip per turn instead of one per entry (a wave walks as long as its slowest lane, and every
 // round trip is 1-2 us of the UE step under load).
-#ifndef RANENV_NARROW_PRIO
-#define RANENV_NARROW_PRIO 1        /* s_setprio of the one-wave class's waves inside the persistent launches (0: none): that class finishes a rollout
-                                       ~7 % behind the two-wave class; issuing first evens them out (gather: K = 20 -2.4 %, K = 200 -0.5 %; streaming: nothing) */
-#endif
-#ifndef RANENV_POISSON_WINDOW
-#define RANENV_POISSON_WINDOW 8     /* 1: the plain walk, one entry per turn */
-#endif
 DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsigned long long u)
 {
     int k = guide[u >> 58];
-#if RANENV_POISSON_WINDOW <= 1
-    while (k < 255 && cdf[k] <= u) k++;
-#else
-    constexpr int WIN = RANENV_POISSON_WINDOW;
+    constexpr int WIN = 8;
     for (;;) {
         unsigned long long c[WIN];
 #pragma unroll
@@ -582,7 +532,6 @@ DEVFN int poisson_draw(const unsigned long long *cdf, const uint8_t *guide, unsi
         k += adv;
         if (adv < WIN) break;
     }
-#endif
     return k;
 }
 

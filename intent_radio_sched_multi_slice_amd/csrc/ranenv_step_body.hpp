@@ -82,12 +82,10 @@ struct SharedCore {
     unsigned msk[NP][2];              // per slice, one bit per UE position, set with LDS atomic ORs by the slice's UEs and read as ONE word:
                                       // [0] the UE's buffer is not empty, [1] its PF / MT value is non-zero.  All zero between two allocations
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
-#if RANENV_OBS_STAGE
     // this TTI's observation rows, staged here and written out by wave 0 as whole lines: written one float per lane and
     // instruction they were ~170 partial-line store requests per env (profiles/r02_pmc_memsys.txt)
     float ob_inter[NP * 10];
     float ob_intra[NP * (2 * NP + 9)];
-#endif
 };
 
 // Workgroup barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its global loads and
@@ -96,20 +94,13 @@ struct SharedCore {
 // global memory.  Where global memory IS handed over -- to the next TTI of the same workgroup without a warm entry, or to another
 // workgroup (persistent rollout) -- full_sync() below is used: __syncthreads() alone is NOT enough, the compiler's
 // workgroup-scope fence waits for lgkmcnt only (no vmcnt(0) outside tgsplit mode: ADVICE r4, seen in the shipped ISA).
-#ifndef RANENV_LDS_BARRIER
-#define RANENV_LDS_BARRIER 1
-#endif
 // `narrow`: this wave is a workgroup of its own inside a two-wave block (ranenv_core_kernel_mixed: two one-wave envs per block):
 // its exchanges through LDS are between its own lanes, so it waits for its LDS operations and must NOT take part in a block
 // barrier -- the block's other wave steps another env, or has left.
 DEVFN void wg_sync(const bool narrow = false)
 {
     if (narrow) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
-#if RANENV_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 DEVFN void full_sync(const bool narrow = false)      // every memory operation of this wave is complete (stores acknowledged by L2), then the barrier
 {
@@ -136,7 +127,8 @@ template <int PACK = 1, typename T> DEVFN T &row_at(T *array, size_t row_bytes, 
         asm volatile("" : "+s"(row));
         return *(T *)(row + lane_bytes);
     } else {
-        const unsigned off = (unsigned)row_bytes + lane_bytes;
+        unsigned off = (unsigned)row_bytes + lane_bytes;
+        asm volatile("" : "+v"(off));              // (the 64-bit address is formed at every use, not carried from the load to the store)
         return *(T *)((char *)array + off);
     }
 }
@@ -146,12 +138,9 @@ template <int PACK = 1, typename T> DEVFN T &row_at(T *array, size_t row_bytes, 
 // (streaming rollout -2...-3 %).  In the SE gather builds, which stream no tile, the same goes for what the kernel WRITES and will not read
 // again soon (observation rows, raw outputs, age-list and window-ring entries; gather -3.7 %; no gain for the streaming builds, so they
 // keep plain stores) and for the sidecar reads.
-#ifndef RANENV_NT_STORES
-#define RANENV_NT_STORES 1         /* 0: plain stores in the gather builds too */
-#endif
 template <bool NT, typename T> DEVFN void nt_store(T &dst, const T v)
 {
-    if constexpr (NT && RANENV_NT_STORES != 0) {
+    if constexpr (NT && RANENV_CACHE_HINTS != 0) {
         if constexpr (sizeof(T) == 8 && !std::is_floating_point<T>::value && !std::is_integral<T>::value)      // (int2: as one 8-byte word)
             __builtin_nontemporal_store(__builtin_bit_cast(long long, v), (long long *)&dst);
         else
@@ -416,7 +405,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // round trip and the age-list ones.  For the whole-row streaming build it also frees the way for the tile: memory operations
     // retire in issue order, so the burst of the next TTI's tile may only follow the TTI's last dependent load -- with the UE step
     // loading nothing the burst moves from behind the UE step to right behind the stream phase.
-    constexpr bool CARRY = PERSIST && MODE == MODE_STEP && PACK == 1 && ((!GATHER && NQ >= 8) || (GATHER && RANENV_GATHER_CARRY != 0));
+    constexpr bool CARRY = PERSIST && MODE == MODE_STEP && PACK == 1 && !GATHER && NQ >= 8;
     // MIX (ranenv_core_kernel_mixed): a two-wave block steps either one env of more than 64 slice members with both waves, or --
     // `narrow` -- two envs of at most 64, one per wave, each wave a workgroup of its own: its own LDS image, lanes counted from its
     // own first lane, no block barrier (wg_sync(narrow))
@@ -448,7 +437,6 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     unsigned long long stamp_prev = 0;
 #endif
     RANENV_STAMP(0);
-#if RANENV_COLD_ARGS
     // The kernel's argument block, read in place: a field that only a late role needs is fetched there (one scalar load)
     // instead of sitting in -- or being spilled from -- SGPRs since kernel entry.  (The laundering keeps the compiler from
     // merging these loads with the by-value copy it loads up front.)
@@ -456,9 +444,6 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kc));
 #define COLD(f) (kc->f)
-#else
-#define COLD(f) (p.f)
-#endif
     ranenv_episode ep;
     int t, hlen, npush, se_pos, trf_pos;
     if (!warm) {
@@ -483,6 +468,13 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     const int sc = ep.scenario;
     se_pos = se_pos < ep.se_len ? se_pos : 0;
     trf_pos = trf_pos < ep.trf_len ? trf_pos : 0;
+    // (a packed wave holds the episode descriptor per lane: the traffic row's byte offset -- below 4 GB there, pack_fits_32 -- as ONE
+    // register from here to the load behind the stream, instead of the 64-bit base and the position)
+    unsigned trf_row32 = 0;
+    if constexpr (PACK == 2) {
+        trf_row32 = (unsigned)(((size_t)ep.trf_base + (size_t)trf_pos) * (size_t)p.U * 4);
+        asm volatile("" : "+v"(trf_row32));          // (formed here, not re-derived at the use from operands kept alive for it)
+    }
     const int hlen_old = hlen;                                // window length the allocation sees
     const bool clear_hist = MODE == MODE_RESET && (p.flags & RANENV_F_CLEAR_HISTORY_ON_RESET);
     if (clear_hist) hlen = 0;
@@ -559,13 +551,14 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if (hlen == D) { old_s = *ring_s(); old_d = *ring_d(); }
         if (MODE != MODE_RESET && !gen_traffic)
             traffic = p.traffic_bits ? row_at<PACK>(p.traffic_bits, er8, u8)
-                                     : (double)row_at<PACK>(p.trf_pool, ((size_t)ep.trf_base + (size_t)trf_pos) * U * 4, u4);
+                                     : (double)row_at<PACK>(p.trf_pool, PACK == 2 ? (size_t)trf_row32 : ((size_t)ep.trf_base + (size_t)trf_pos) * U * 4, u4);
     };
-    // When the rest of the UE's state is requested: behind the stream by default (see RANENV_DEFER_STATE: registers), but at
+    // When the rest of the UE's state is requested: behind the stream by default (~20 registers fewer while the tile streams: with 8
+    // loads in flight per lane the kernel fits 96 VGPRs = 5 waves per SIMD without spills, profiles/r02_ab_log.txt), but at
     // entry in the build that has registers to spare (the whole-row queue of a batch at <= 2 waves per SIMD): there its round
     // trip -- 1.5-2 us of every chain when exposed -- runs under the allocation and the stream.
-    constexpr int DEFER = (!GATHER && NQ >= 8) ? 0 : RANENV_DEFER_STATE;
-    if constexpr (DEFER == 0) rest_of_state();
+    constexpr bool STATE_AT_ENTRY = !GATHER && NQ >= 8;
+    if constexpr (STATE_AT_ENTRY) rest_of_state();
     if (MODE == MODE_STEP && !warm) sem_prev = UE8(se_mean);
     double sem_tile = 0.0;                          // gather: this tile's mean SE of UE u, from the sidecar
     if (GATHER) sem_tile = row_at<PACK>(p.se_mean_pool, (size_t)tile_no * U * 8, u8);
@@ -582,18 +575,9 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if (tid < S * 3) st_pf = row_at<PACK>(TB_param_f64(p), by_metric + (size_t)sc * S * 24, t8);
         if (tid < S * 2) st_sf = row_at<PACK>(TB_slice_f64(p), (size_t)sc * S * 16, t8);
     }
-    // device policy: this TTI's allocation may have been made at the end of the previous step
-    bool pre = false;
-    if (RANENV_LATE_BUILT && MODE == MODE_STEP && p.scores == nullptr && p.late != 0 && !warm) pre = uni(ST_alloc_gen(p)[e]) == p.alloc_gen;
-#if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8    /* ablations: 8 = no allocation and no obs tail; 10 = allocation + tail only; 6 = entry + stream only (ranges from the stored allocation, sums written out); 7 = no allocation */
-    if (MODE == MODE_STEP) pre = true;
+#if RANENV_DIAG == 7      /* ablation: no allocation -- the UE's range of the previous TTI stands in */
+    if (MODE == MODE_STEP) { rb_start = UE4(rb_start); rb_count = UE4(rb_count); }
 #endif
-    if (pre) {
-        rb_start = UE4(next_rb_start); rb_count = UE4(next_rb_count);
-#if RANENV_DIAG != 9 && RANENV_DIAG != 12
-        if (tid < S) row_at<PACK>(ST_policy_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u) = row_at<PACK>(ST_next_scores(p), (size_t)e * S * 8, (unsigned)tid * 8u);
-#endif
-    }
     const int episode_no = warm ? uni(cy.episode_no) : (gen_traffic ? uni(ST_episode_no(p)[e]) : 0);
     asm volatile("" ::: "memory");                 // keep the SE loads behind the loads above
     // SE_AHEAD (the whole-row build of a batch at <= 2 waves per SIMD): the queue lives in the caller's loop, and a TTI that is
@@ -628,7 +612,11 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     RANENV_STAMP(1);
 
     // ---- (0) this TTI's allocation --------------------------------------------------------------------
-    if (MODE == MODE_STEP && !pre)
+    // (behind a condition the optimiser cannot see through -- always true: without it the scheduler moves address arithmetic of the later
+    // roles up across the allocation, their registers are alive through it, and the builds at the 96-register limit spill)
+    int do_alloc = 1;
+    asm volatile("" : "+s"(do_alloc));
+    if (MODE == MODE_STEP && RANENV_DIAG != 7 && do_alloc != 0)
         alloc_front<NP, PACK>(p, sh, tid, e, hlen_old, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_prev,
                     rb_start, rb_count, ST_policy_scores(p), narrow);
     RANENV_STAMP(2);
@@ -650,33 +638,19 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
 
     // ---- (1) SE row sums -------------------------------------------------------------------------
     double my_full = 0.0, my_part = 0.0;
-    auto hook = [&]() {
-        if constexpr (DEFER == 1) rest_of_state();
-    };
+    auto hook = []() {};
     if constexpr (GATHER) {
-#if RANENV_GATHER_STATE_FIRST
-        rest_of_state();          // requested ahead of the gather: both latencies run together
-#endif
         if (MODE == MODE_STEP) my_part = gather_part<PACK, GDEPTH, PE>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count, PE ? COLD(bw_per_rb) : 1.0);
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
-#if RANENV_DIAG == 1 || RANENV_DIAG == 10
-        { float x0[8]; se1.take(0, x0, 0); my_full = (double)x0[0] + (double)us1; my_part = (double)uc1; }
-#elif RANENV_DIAG == 2
-        row_sums(se1, R, [=](int r) { return false; }, my_full, my_part, hook); my_part = (double)(us1 + uc1);
-#else
         row_sums<PE>(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part, hook, PE ? COLD(bw_per_rb) : 1.0);
-#endif
     } else if constexpr (MODE == MODE_DENSE) {
         const uint8_t *mrow = p.dense + ((size_t)e * U + u) * R;
         row_sums<PE>(se1, R, [=](int r) { return mrow[r] != 0; }, my_full, my_part, hook, PE ? COLD(bw_per_rb) : 1.0);
     } else {
         row_sums(se1, R, [](int) { return false; }, my_full, my_part, hook);
     }
-    if constexpr (DEFER == 2) {
-        if (!(GATHER && RANENV_GATHER_STATE_FIRST))
-            rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
-    }
+    if constexpr (!STATE_AT_ENTRY) rest_of_state();        // after the stream: its latency is exposed, its registers were free for the queue
     if constexpr (SE_AHEAD && CARRY) {
         // The next TTI's tile of this env (the position it will derive itself: cy.se_pos below), requested as soon as the queue's
         // registers are free: in a carried TTI nothing the UE step needs is loaded behind it (in the first TTI of a chunk the UE step's
@@ -699,12 +673,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     int sent_u = 0, drop_u = 0;              // this UE's packets sent / dropped (episode metrics)
     bool prev_empty = total == 0;
     if (total != 0 && !((double)total > 2e-8 * (double)max_pkts)) prev_empty = d_isclose((double)total / (double)max_pkts, 0.0);
-#if RANENV_DIAG == 6
-    if (act) { UE8(se_mean) = my_full; UE8(queue_age_sum) = (long long)my_part; }
-#endif
-#if RANENV_DIAG == 6
-    if (false) {
-#elif RANENV_DIAG == 3 || RANENV_DIAG == 5 || RANENV_DIAG == 10
+#if RANENV_DIAG == 3      /* ablation: no UE step (the condition is never true, and the compiler cannot know) */
     if (act && my_full < -1.0) {
 #else
     if (act) {
@@ -905,17 +874,13 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             srow(sh, slc, 3)[ue_pos] = se_mean_new;
             sh.cnt[slc][ue_pos] = rb_count;
             if (COLD(obs_intra) && ue_pos < Us) {                                          // per-UE entries (:186-200)
-#if RANENV_OBS_STAGE
                 float *oa = sh.ob_intra + slc * W;
-#else
-                float *oa = COLD(obs_intra) + ((size_t)e * S + slc) * W;
-#endif
                 oa[9 + ue_pos] = (float)occ_new;
                 oa[9 + Us + ue_pos] = (float)ddiv(se_mean_new, COLD(norm_se));
             }
         }
     }
-    if (MODE != MODE_RESET && (RANENV_METRICS && COLD(acc) != nullptr)) {
+    if (MODE != MODE_RESET && COLD(acc) != nullptr) {
         // episode metrics: packet totals of the env, one add per wave (integers in doubles: exact in any order)
         const double ws = PACK == 2 ? half_sum_f64((double)sent_u) : wave_sum_f64((double)sent_u);
         const double wd = PACK == 2 ? half_sum_f64((double)drop_u) : wave_sum_f64((double)drop_u);
@@ -933,12 +898,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     wg_sync(narrow);
     RANENV_STAMP(6);
     do {
-#if RANENV_DIAG == 4 || RANENV_DIAG == 5 || RANENV_DIAG == 6 || RANENV_DIAG == 8   /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
-#if RANENV_DIAG == 6
-    if (true) {
-#else
+#if RANENV_DIAG == 4      /* ablation: no observation tail, but the per-env counters move on (tiles keep changing) */
     if (my_full >= -1.0) {
-#endif
         if (tid == 0) {
             ST_step_no(p)[e] = (MODE == MODE_RESET) ? 0 : t + 1; ST_hist_len(p)[e] = hlen_new; ST_n_push(p)[e] = npush + 1 == D ? 0 : npush + 1;
             ST_push_total(p)[e] = ptot + 1;
@@ -1000,20 +961,12 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         const float a0 = (float)am[0], a1 = (float)am[1], a2 = (float)am[2];
         const float tr = (float)ddiv(traffic_req, COLD(norm_traffic)), nu = (float)ddiv((double)n, COLD(norm_ues));
         if (COLD(obs_inter)) {                                                         // :160-173
-#if RANENV_OBS_STAGE
             float *oi = sh.ob_inter + spos * 10;
-#else
-            float *oi = COLD(obs_inter) + ((size_t)e * S + spos) * 10;
-#endif
             oi[0] = o0; oi[1] = o1; oi[2] = o2; oi[3] = a0; oi[4] = a1; oi[5] = a2;
             oi[6] = (float)priority; oi[7] = tr; oi[8] = nu; oi[9] = (float)ddiv(se_slice, COLD(norm_se));
         }
         if (COLD(obs_intra)) {
-#if RANENV_OBS_STAGE
             float *oa = sh.ob_intra + s * W;
-#else
-            float *oa = COLD(obs_intra) + ((size_t)e * S + s) * W;
-#endif
             oa[0] = o0; oa[1] = o1; oa[2] = o2; oa[3] = a0; oa[4] = a1; oa[5] = a2;
             oa[6] = (float)ddiv((double)rbs_s, (double)R); oa[7] = tr; oa[8] = nu;
             for (int k = n; k < Us; k++) { oa[9 + k] = 0.0f; oa[9 + Us + k] = 0.0f; }
@@ -1053,7 +1006,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     // episode metrics: distance to fulfilment = sum of the negative slice drifts (entries beyond S are 0), all slices and
     // priority slices (priority is 0 or 1), as a fixed tree over the 16 lanes
     double dist = 0.0, prio_dist = 0.0;
-    if (MODE != MODE_RESET && (RANENV_METRICS && COLD(acc) != nullptr)) {
+    if (MODE != MODE_RESET && COLD(acc) != nullptr) {
         dist = row16_sum_f64(fmin(my_ao, 0.0)); prio_dist = row16_sum_f64(fmin(my_ao * my_pr, 0.0));
     }
     const bool my_sel = tid < S && (mode_sel == 0 ? true : (mode_sel == 1 ? (my_ao * my_pr < 0.0) : (my_ao < 0.0)));
@@ -1070,7 +1023,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         // Episode metrics (ranenv_enable_metrics): running sums of what the paper's evaluation reads per TTI
         // (results/gen_results.py:874-1022: slices in violation, distance to fulfilment, all slices / priority slices
         // only), of the inter-slice reward and of the packet totals.  One writer per env and TTI; fire-and-forget adds.
-        if ((RANENV_METRICS && COLD(acc) != nullptr)) {
+        if (COLD(acc) != nullptr) {
             double *a = COLD(acc) + (size_t)e * 8;
             if (MODE == MODE_RESET) {
 #pragma unroll
@@ -1099,7 +1052,6 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         if (COLD(done)) COLD(done)[e] = (MODE != MODE_RESET && step_new >= max_steps_e) ? 1 : 0;
     }
     } while (0);
-#if RANENV_OBS_STAGE
     // wave 0 writes the staged observation rows out, a float per lane and whole lines per instruction (the per-UE entries were
     // staged before the barrier in front of (3), the per-slice ones by this wave's first 16 lanes just now)
     if (tid < WAVE && (COLD(obs_inter) || COLD(obs_intra))) {
@@ -1113,23 +1065,8 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
             for (int i = tid; i < S * W; i += LW) nt_store<GATHER>(row_at<PACK>(dst, 0, (unsigned)i * 4u), sh.ob_intra[i]);
         }
     }
-#endif
     RANENV_STAMP(7);
 
-    // ---- (0') the next TTI's allocation, from the state this step leaves behind ----------------------
-    bool late = false;
-    if (RANENV_LATE_BUILT && MODE == MODE_STEP) late = p.scores == nullptr && (p.late == 2 || (p.late == 1 && (((unsigned)e * 0x9E3779B1u) >> 16 & 1u)));
-#if RANENV_DIAG == 6 || RANENV_DIAG == 7 || RANENV_DIAG == 8
-    if (MODE == MODE_STEP) late = false;
-#endif
-    if (late) {
-        wg_sync(narrow);                     // (3) is done with the per-slice rows
-        int ns = 0, nc = 0;
-        alloc_front<NP, PACK>(p, sh, tid, e, hlen_new, act && slc >= 0, slc, ue_pos, total, max_pkts, pkt_size, win_sent, sem_new,
-                    ns, nc, ST_next_scores(p), narrow);
-        if (act) { UE4(next_rb_start) = ns; UE4(next_rb_count) = nc; }
-    }
-    if (tid == 0) ST_alloc_gen(p)[e] = late ? p.alloc_gen : 0;
     RANENV_STAMP(8);
     if (MODE == MODE_STEP) {         // for the next TTI of this launch, if there is one (what tid 0 has just stored, and this lane's own)
         cy.ep = ep; cy.t = t + 1; cy.hlen = hlen_new; cy.npush = npush + 1 == D ? 0 : npush + 1;
@@ -1178,9 +1115,9 @@ DEVFN void step_loop(const KP &p)
             asm volatile("" : "+s"(kc));
             if (step_body<MODE_X, NQ, GATHER, NP, false, PACK, MIX>(*kc, cy, warm, MIX ? e_mix : kc->e0 + (int)blockIdx.x * PACK, nullptr, false, false, narrow)) return;
             if (k + 1 < n) {
-                // The next TTI takes over in registers what it would otherwise load back (StepCarry) -- unless it has to look
-                // for an allocation made ahead (RANENV_LATE) -- and then only LDS has to be handed over between the waves.
-                warm = MANY && RANENV_WARM_ENTRY && kc->late == 0;
+                // The next TTI takes over in registers what it would otherwise load back (StepCarry): only LDS has to be handed over
+                // between the waves.
+                warm = MANY;
                 if (warm) wg_sync(narrow); else full_sync(narrow);
             }
         }
@@ -1218,7 +1155,8 @@ struct PersistLocal { int item, next, keep, fresh_mask, xcc, pad; };
 enum { PERSIST_EXIT = -1, PERSIST_NONE = -2 };
 
 // (statistics of the queues, one fire-and-forget add per event from lane 0: ranenv_get_option "persist_stat_*")
-#define PSTAT(k) ((void)__hip_atomic_fetch_add(&p.p_ctl->stat[pl.xcc][k], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define PSTAT(k) ((void)__hip_atomic_fetch_add(&p.p_ctl->stat[xcc][k], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define XCC_OF(pl) const int xcc = __builtin_amdgcn_readfirstlane((pl).xcc)      /* (one lane runs these functions: a scalar, not a register pair per use) */
 DEVFN unsigned pq_ld(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEVFN int pq_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1226,8 +1164,9 @@ DEVFN int pq_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, _
 template <typename P> DEVFN int persist_try_fresh(const P &p, PersistLocal &pl)
 {
     PersistCtl *c = p.p_ctl;
+    XCC_OF(pl);
     for (int s8 = 0; s8 < 8 && pl.fresh_mask != 0; s8++) {
-        const int x = (pl.xcc + s8) & 7;
+        const int x = (xcc + s8) & 7;
         if (!(pl.fresh_mask >> x & 1)) continue;
         const unsigned j = __hip_atomic_fetch_add(&c->fresh[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long i = (long long)x + 8ll * (long long)j;
@@ -1247,11 +1186,12 @@ template <typename P> DEVFN int persist_try_fresh(const P &p, PersistLocal &pl)
 template <typename P> DEVFN int persist_try_pop(const P &p, const PersistLocal &pl)
 {
     PersistCtl *c = p.p_ctl;
-    if (pq_ldi(&c->q[pl.xcc].avail) <= 0) return PERSIST_NONE;
-    const int a = __hip_atomic_fetch_add(&c->q[pl.xcc].avail, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a <= 0) { __hip_atomic_fetch_add(&c->q[pl.xcc].avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return PERSIST_NONE; }
-    const unsigned h = __hip_atomic_fetch_add(&c->q[pl.xcc].head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long *slot = p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (h & (unsigned)(p.p_cap - 1));
+    XCC_OF(pl);
+    if (pq_ldi(&c->q[xcc].avail) <= 0) return PERSIST_NONE;
+    const int a = __hip_atomic_fetch_add(&c->q[xcc].avail, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a <= 0) { __hip_atomic_fetch_add(&c->q[xcc].avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return PERSIST_NONE; }
+    const unsigned h = __hip_atomic_fetch_add(&c->q[xcc].head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *slot = p.p_slots + (size_t)xcc * (size_t)p.p_cap + (h & (unsigned)(p.p_cap - 1));
     unsigned long long ent = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned spin = 0; (unsigned)(ent >> 32) != h + 1u; spin++) {
         PSTAT(4);
@@ -1264,21 +1204,20 @@ template <typename P> DEVFN int persist_try_pop(const P &p, const PersistLocal &
         ent = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PSTAT(2);
-#ifndef RANENV_PERSIST_NO_ACQUIRE      /* timing experiments only: results may be stale without it */
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // buffer_inv sc1: this CU's L1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     return (int)(unsigned)ent;
 }
 
 template <typename P> DEVFN void persist_push(const P &p, const PersistLocal &pl, int item)
 {
     PersistCtl *c = p.p_ctl;
+    XCC_OF(pl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (every wave waited for its stores in front of the chunk-end barrier: full_sync)
-    const unsigned idx = __hip_atomic_fetch_add(&c->q[pl.xcc].tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long *slot = p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (idx & (unsigned)(p.p_cap - 1));
+    const unsigned idx = __hip_atomic_fetch_add(&c->q[xcc].tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long *slot = p.p_slots + (size_t)xcc * (size_t)p.p_cap + (idx & (unsigned)(p.p_cap - 1));
     __hip_atomic_store(slot, ((unsigned long long)(idx + 1u) << 32) | (unsigned)item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&c->q[pl.xcc].avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&c->q[xcc].avail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PSTAT(1);
 }
 
@@ -1302,6 +1241,7 @@ template <typename P> DEVFN int persist_pull(const P &p, PersistLocal &pl)
 template <typename P> DEVFN int persist_finish(const P &p, PersistLocal &pl, int e, int done, int n_tti)
 {
     PersistCtl *c = p.p_ctl;
+    XCC_OF(pl);
     if (done >= n_tti) return 0;
     if (pq_ldi(&c->abort) != 0) {        // a wait gave up somewhere in this class: the env is dropped here, and the host is told (again)
         if (p.p_err) __hip_atomic_store(p.p_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1309,12 +1249,12 @@ template <typename P> DEVFN int persist_finish(const P &p, PersistLocal &pl, int
     }
     const int fresh = persist_try_fresh(p, pl);
     if (fresh == PERSIST_NONE) {
-        if (pq_ldi(&c->q[pl.xcc].avail) <= 0) { PSTAT(0); return 1; }    // nobody is waiting
-        const unsigned h = pq_ld(&c->q[pl.xcc].head);
+        if (pq_ldi(&c->q[xcc].avail) <= 0) { PSTAT(0); return 1; }    // nobody is waiting
+        const unsigned h = pq_ld(&c->q[xcc].head);
         // Somebody is -- but a swap only helps when the env at the head of the queue is BEHIND this one: with every
         // finisher swapping, every chunk of every env would go through the queue; this way a round of chunks costs one swap per
         // waiting env (a racy look at the head entry: a heuristic, whichever way it goes the state stays consistent).
-        const unsigned long long ent = __hip_atomic_load(p.p_slots + (size_t)pl.xcc * (size_t)p.p_cap + (h & (unsigned)(p.p_cap - 1)),
+        const unsigned long long ent = __hip_atomic_load(p.p_slots + (size_t)xcc * (size_t)p.p_cap + (h & (unsigned)(p.p_cap - 1)),
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(ent >> 32) == h + 1u && (int)((unsigned)ent >> PERSIST_ENV_BITS) >= done) { PSTAT(0); return 1; }
     }
@@ -1377,10 +1317,10 @@ DEVFN void persist_loop()
                 // another TTI of this env follows in this launch and enters warm if this workgroup makes it: the next one of the chunk, or
                 // -- the workgroup keeps its env at most chunk ends -- the next chunk's first (what is requested ahead for it is wasted
                 // when the env changes hands)
-                const bool ahead = RANENV_WARM_ENTRY != 0 && done + k + 1 < n_tti;
+                const bool ahead = done + k + 1 < n_tti;
                 (void)step_body<MODE_STEP, NQ, GATHER, NP, true>(*kc, cy, warm, e, &seq, se_ready, ahead);
                 se_ready = ahead;
-                if (k + 1 < n) { warm = RANENV_WARM_ENTRY != 0; if (warm) wg_sync(); else full_sync(); }
+                if (k + 1 < n) { warm = true; wg_sync(); }
             }
             done += n;
             // Hand-over point: EVERY wave waits for its own stores to be acknowledged by the XCD's L2 (explicit vmcnt(0): the
@@ -1393,18 +1333,18 @@ DEVFN void persist_loop()
             }
             __syncthreads();
             if (uni(pl.keep) == 0) break;
-            warm = RANENV_WARM_ENTRY != 0;           // `cy` is what the chunk's last TTI left
+            warm = true;                             // `cy` is what the chunk's last TTI left
         }
     }
 }
 
-#ifndef RANENV_PERSIST_WAVES_PER_EU
-#define RANENV_PERSIST_WAVES_PER_EU 5
+#ifndef RANENV_NARROW_PRIO
+#define RANENV_NARROW_PRIO 1        /* s_setprio of the one-wave class's waves inside the persistent launches (0: none): that class finishes a rollout
+                                       ~7 % behind the two-wave class; issuing first evens them out (gather: K = 20 -2.4 %, K = 200 -0.5 %; streaming: nothing) */
 #endif
-#ifndef RANENV_PERSIST_GATHER_WAVES
-#define RANENV_PERSIST_GATHER_WAVES 5
-#endif
-#define RANENV_PERSIST_WPE ((NP == 16) ? 4 : (GATHER ? RANENV_PERSIST_GATHER_WAVES : RANENV_PERSIST_WAVES_PER_EU))
+// waves per SIMD the builds are compiled for: 5 (96 VGPRs) everywhere except the 16-wide row builds of multi-TTI launches (4: they keep
+// 16-entry rows of doubles alive in the allocation and would spill at 96), the small-batch and packed builds (4) and the whole-row builds (2)
+#define RANENV_PERSIST_WPE ((NP == 16) ? 4 : 5)
 template <bool GATHER, int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_PERSIST_WPE, RANENV_PERSIST_WPE))) ranenv_persist_kernel(const KP p)
 {
@@ -1414,22 +1354,19 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RA
     // the one-wave class finishes a rollout after the two-wave class (its envs have half the loads in flight): its waves issue first
     if (blockDim.x == WAVE) __builtin_amdgcn_s_setprio(RANENV_NARROW_PRIO);
 #endif
-    persist_loop<GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP>();
+    persist_loop<GATHER ? 1 : SE_DEPTH_LEAN, GATHER, NP>();
 #endif
 }
 
 // The same for a batch that leaves the chip at <= 2 waves per SIMD (BASELINE configs[1], B 1024): 256 VGPRs are there for the
 // taking, so a lane keeps its whole SE row in flight (16 groups of 8 loads): the stream phase of a workgroup's chain is one
 // memory latency instead of four (profiles/r04_ab_log.txt: 23.4 against 26.6 us per TTI).  Streaming only.
-#ifndef RANENV_SE_DEPTH_TINY
-#define RANENV_SE_DEPTH_TINY 17       /* R = 135: 16 groups of 8 + the tail group -- the whole row, no load is requested inside the stream phase */
-#endif
 template <int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ranenv_persist_kernel_tiny(const KP p)
 {
     (void)p;
 #if RANENV_DIAG == 0 || RANENV_DIAG == 12
-    persist_loop<RANENV_SE_DEPTH_TINY, false, NP>();
+    persist_loop<SE_DEPTH_TINY, false, NP>();
 #endif
 }
 
@@ -1439,47 +1376,34 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2,
 template <int NP>
 __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ranenv_core_kernel_tiny1(const KP p)
 {
-    step_loop<MODE_STEP, RANENV_SE_DEPTH_TINY, false, NP, false>(p);
+    step_loop<MODE_STEP, SE_DEPTH_TINY, false, NP, false>(p);
 }
 // Two builds of the step kernel.  A batch that fills the machine (more workgroups than 8 per CU) runs the lean one:
 // 96 VGPRs = 5 waves per SIMD = 10 workgroups per CU, 16 SE loads in flight per lane (8 until the build stopped hoisting
 // at machine level, which freed the registers for the second group) -- occupancy hides more latency than a still deeper
 // queue (measured, profiles/r02_ab_log.txt, r03_ab_log.txt).  A small batch is resident at once whatever the register
 // count, so it takes the build with 128 VGPRs and 32 loads in flight.
-#ifndef RANENV_WAVES_PER_EU
-#define RANENV_WAVES_PER_EU 5      /* experiment knob: waves per SIMD of the lean build (0 = compiler's choice) */
-#endif
-#if RANENV_WAVES_PER_EU > 0
-#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(RANENV_WAVES_PER_EU, RANENV_WAVES_PER_EU)))
-#else
-#define RANENV_CORE_ATTR
-#endif
+#define RANENV_CORE_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
 // (MANY: a launch of several TTIs, ranenv_rollout only, runs a build of its own -- the one-TTI build stays free of the
 // warm entry's second path through the role, which costs it 1-2 %)
 template <int MODE, int NP, bool MANY>
 __global__ void __launch_bounds__(CORE_NT) RANENV_CORE_ATTR ranenv_core_kernel(const KP p)
 {
-    step_loop<MODE, ((MODE & 3) == MODE_DENSE || NP == 16) ? 1 : RANENV_SE_DEPTH, false, NP, MANY>(p);
+    step_loop<MODE, ((MODE & 3) == MODE_DENSE || NP == 16) ? 1 : SE_DEPTH_LEAN, false, NP, MANY>(p);
 }
-#ifndef RANENV_SMALL_WAVES_PER_EU
-#define RANENV_SMALL_WAVES_PER_EU 4
-#endif
 template <int MODE, int NP, bool MANY>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_SMALL_WAVES_PER_EU, RANENV_SMALL_WAVES_PER_EU))) ranenv_core_kernel_small(const KP p)
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_small(const KP p)
 {
-    step_loop<MODE, RANENV_SE_DEPTH_SMALL, false, NP, MANY>(p);
+    step_loop<MODE, SE_DEPTH_SMALL, false, NP, MANY>(p);
 }
 // The SE gather build (ranenv_set_se_mode): no tile stream, so no queue registers; one build for every batch size.
-#ifndef RANENV_GATHER_WAVES_PER_EU
-#define RANENV_GATHER_WAVES_PER_EU 5
-#endif
 // (the 16-wide row build keeps 16-entry rows of doubles alive in the allocation and does not fit 96 registers with the per-TTI loop
 // around it -- 2...10 spilled VGPRs -- so it is built for 4 waves per SIMD: S or Us above 10 is not a BASELINE size, and a spill in
 // every TTI costs more than the fifth wave gains, profiles/r03_ab_log.txt.  No kernel of the library has scratch:
 // tests/test_kernel_resources.py reads the shipped code object's metadata)
 #define RANENV_WPE_NP(w) ((NP == 16 && MANY) ? 4 : (w))
 template <int MODE, int NP, bool MANY>
-__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU), RANENV_WPE_NP(RANENV_GATHER_WAVES_PER_EU))))
+__global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RANENV_WPE_NP(5), RANENV_WPE_NP(5))))
 ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP, MANY>(p); }
 // Every build above exists for three row widths NP (see np_sum_lds): 8, 10 (BASELINE's 10 slices / 10 UEs per slice), 16.
 
@@ -1491,23 +1415,17 @@ ranenv_core_kernel_gather(const KP p) { step_loop<MODE, 1, true, NP, MANY>(p); }
 template <int NP, bool MANY, bool GATHER>
 __global__ void __launch_bounds__(2 * WAVE) RANENV_CORE_ATTR ranenv_core_kernel_mixed(const KP p)
 {
-    step_loop<MODE_STEP, GATHER ? 1 : RANENV_SE_DEPTH, GATHER, NP, MANY, 1, true>(p);
+    step_loop<MODE_STEP, GATHER ? 1 : SE_DEPTH_LEAN, GATHER, NP, MANY, 1, true>(p);
 }
 
 // Packed waves (round 4): envs of at most 32 UEs and 8 slices -- the reference's own size, S 5 / U 25 -- leave 39 of a wave's 64 lanes
 // idle, and the chip holds as many waves as it holds; one wave steps TWO envs (lanes 0-31 / 32-63, step_body's PACK = 2): half as many
 // waves per env-step.  What is wave-uniform in the other builds is per-lane here (more registers: 4 waves per SIMD), so it is a build
 // of its own, for step launches of an even number of envs; reset and dense launches keep one env per wave (same state layout).
-#ifndef RANENV_PACK_NQ
-#define RANENV_PACK_NQ 2           /* 8-RB groups in flight per lane in the packed streaming builds */
-#endif
-#ifndef RANENV_PACK_WPE
-#define RANENV_PACK_WPE 4
-#endif
 template <int NP, bool MANY, bool GATHER>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(RANENV_PACK_WPE, RANENV_PACK_WPE))) ranenv_core_kernel_packed(const KP p)
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) ranenv_core_kernel_packed(const KP p)
 {
-    step_loop<MODE_STEP, GATHER ? (MANY ? 1 : 0) : RANENV_PACK_NQ, GATHER, NP, MANY, 2>(p);        // (one-TTI gather build: gather depth 1, it has no register to spare)
+    step_loop<MODE_STEP, GATHER ? (MANY ? 1 : 0) : SE_DEPTH_PACKED, GATHER, NP, MANY, 2>(p);        // (one-TTI gather build: gather depth 1, it has no register to spare)
 }
 
 }  // namespace

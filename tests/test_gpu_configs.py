@@ -365,7 +365,7 @@ def test_config2_headline_schedule_with_the_device_traffic_generator_vs_oracle()
 # ------------------------------------------------------------------------------------------------------------------
 def _bench_options(env):
     """the defaults bench.py runs under, whatever knob the suite runs under"""
-    for k, v in (("compact", 1), ("fuse", 0), ("persist", -1), ("persist_chunk", 10), ("persist_grid", 0), ("pack", 1), ("mix", 1), ("late", 0)):
+    for k, v in (("compact", 1), ("fuse", 0), ("persist", -1), ("persist_chunk", 10), ("persist_grid", 0), ("pack", 1), ("mix", 1)):
         env.set_option(k, v)
     for i in range(3):
         env.set_option(f"fuse_first{i}", 0)

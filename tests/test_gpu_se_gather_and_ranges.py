@@ -509,7 +509,7 @@ def test_options_are_set_and_read_back_and_unknown_keys_fail():
     from intent_radio_sched_multi_slice_amd._lib import RanEnvError
     a = _bench_like(64, False)
     env = a.env
-    for key, val in (("compact", 0), ("fuse", 7), ("late", 2), ("row_width", 16), ("small_batch", 1), ("fuse_first1", 4), ("persist", 1), ("persist_chunk", 7)):
+    for key, val in (("compact", 0), ("fuse", 7), ("row_width", 16), ("small_batch", 1), ("fuse_first1", 4), ("persist", 1), ("persist_chunk", 7)):
         env.set_option(key, val)
         assert env.get_option(key) == val, key
     assert env.get_option("fuse_first0") == 0

@@ -326,7 +326,7 @@ def test_options_table_in_the_header_matches_the_library_and_the_environment_is_
 def test_packed_waves_are_refused_where_a_32_bit_row_offset_could_wrap():
     """packed waves (two envs per wave) address a per-env row as array base + a 32-bit offset; the guard must cover every
     array addressed that way by its ACTUAL allocation -- the intent-parameter tables are two blocks of NS * S * 24 bytes, the per-UE
-    state slabs 13 / 4 fields of B * U elements, the score rows B * S * 8.  Pure host arithmetic (ranenv_packed_step_fits): no GPU."""
+    state slabs 11 / 4 fields of B * U elements, the score rows B * S * 8.  Pure host arithmetic (ranenv_packed_step_fits): no GPU."""
     import ctypes as C
     from intent_radio_sched_multi_slice_amd import _lib
     lib = _lib.load()
@@ -344,8 +344,8 @@ def test_packed_waves_are_refused_where_a_32_bit_row_offset_could_wrap():
     assert 2 * ns_edge * 5 * 24 < lim or 2 * ns_edge * 5 * 24 == lim
     assert not fits(NS=ns_edge + 1, U=1, Us=1)                   # (U = 1: the per-UE tables, 12 * NS * U * 4, stay below the bound)
     assert fits(NS=ns_edge - 1, U=1, Us=1)
-    # the 4-byte state slab: 13 fields of B * U elements
-    b_edge = lim // (13 * 25 * 4)
+    # the 4-byte state slab: 11 fields of B * U elements
+    b_edge = lim // (11 * 25 * 4)
     assert not fits(B=b_edge + 1) and fits(B=b_edge - 2)
     # the traffic pool and the sidecar of means
     assert not fits(trf=lim // (25 * 4) + 1) and fits(trf=lim // (25 * 4) - 1)
