@@ -47,7 +47,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD, CLOCK_HZ, VALU_CYCLES = 256 * 4, 2.4e9, 4.0   # 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction issues over >= 4 cycles
-PMC_FILE = os.path.join("profiles", "r05_pmc.json")   # rocprofv3 --pmc passes of the schedule timed here (tools/profile_rollout.py, pmc_collect_r4.py, round5_measure.sh)
+PMC_FILE = os.path.join("profiles", "r06_pmc.json")   # rocprofv3 --pmc passes of the schedules timed here (tools/profile_rollout.py, pmc_collect_r4.py, round6_measure.sh)
 REFPY_FILE = os.path.join("profiles", "r04_reference_python.json")   # the reference's own Python, timed in the build container
 SAMPLE_S = 0.020                                      # stepping time sampled per timed variant
 
@@ -278,7 +278,21 @@ def gather_block(env, batch, world, steps, times, kms, parts, pmc):
     return out
 
 
-def other_config_block(cfg, device, args, rank, se_pool, timing):
+def issue_fields(block, t_s):
+    """VALU issue bound of one TTI from a PMC block (SQ_INSTS_VALU per TTI of the batch) against the measured time per TTI."""
+    if not block or not block.get("valu_insts_per_tti"):
+        return {}
+    issue_s = block["valu_insts_per_tti"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ)
+    out = {"valu_insts_per_tti": block["valu_insts_per_tti"], "issue_bound_s": issue_s, "issue_frac": issue_s / t_s,
+           "pmc_source": f"{PMC_FILE} ({block.get('date', 'undated')}; not measured in this run)"}
+    if block.get("wait_any_per_tti") and block.get("wave_cycles_per_tti"):
+        out["wait_any_frac_of_wave_cycles"] = block["wait_any_per_tti"] / block["wave_cycles_per_tti"]
+    if block.get("hbm_bytes_per_tti"):
+        out["traffic_per_tti"] = block["hbm_bytes_per_tti"]
+    return out
+
+
+def other_config_block(cfg, device, args, rank, se_pool, timing, pmc_block=None):
     """One of the other BASELINE configs as a short block: its workload (the resident SE pool re-used where the shape matches),
     warm-up, blocks of exactly K steps of ranenv_rollout under the schedule the library picks for it."""
     import torch
@@ -305,6 +319,10 @@ def other_config_block(cfg, device, args, rank, se_pool, timing):
                          + (", two envs per wave" if (env.U <= 32 and env.get_option("pack")) else ""),
                "persistent": bool(persistent), "partitions": parts, "se_mode": "stream",
                "setup_s": None})
+    if pmc_block and pmc_block.get("batch") == env.B:       # (counters of THIS workload's rollout: which of HBM and VALU issue is nearer)
+        st.update(issue_fields(pmc_block, st["ms_per_step"] * 1e-3))
+        if "issue_frac" in st:
+            st["bound"] = "valu-issue" if st["issue_frac"] >= st["roofline_frac"] else "hbm"
     sync()
     env.close()
     del wl, env
@@ -509,7 +527,7 @@ def main():
         try:
             pj = json.load(open(os.path.join(REPO, PMC_FILE)))
             if pj.get("batch") == batch and pj.get("config") == args.config:
-                pmc = {m: dict(pj[m], date=pj.get("date")) for m in ("stream", "gather", "stream_rollout", "gather_rollout") if m in pj}
+                pmc = {m: dict(pj[m], date=pj.get("date")) for m in ("stream", "gather", "stream_rollout", "gather_rollout", "native_rollout", "config1_rollout") if m in pj}
         except Exception:
             pmc = None
 
@@ -533,7 +551,8 @@ def main():
         others = {}
         for name, cfg in (("1", 1), ("4", 4), ("native", 5)):
             try:
-                others[name] = other_config_block(cfg, device, args, rank, pool if cfg != 5 else None, (sync, barrier, max_over_ranks))
+                others[name] = other_config_block(cfg, device, args, rank, pool if cfg != 5 else None, (sync, barrier, max_over_ranks),
+                                                  (pmc or {}).get({"1": "config1_rollout", "native": "native_rollout"}.get(name, "")))
             except (torch.OutOfMemoryError, _lib.RanEnvError) as e:
                 others[name] = {"skipped": str(e)}
         extras["other_configs"] = others

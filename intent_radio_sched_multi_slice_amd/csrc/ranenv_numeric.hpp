@@ -123,6 +123,13 @@ DEVFN double row16_sum_f64(double x)  // the same for a double (two 32-bit moves
     x += rot(x, std::integral_constant<int, 0x124>{}); x += rot(x, std::integral_constant<int, 0x128>{});
     return x;
 }
+// max of two doubles that are not NaN: ONE v_max_f64 (fmax() canonicalises both operands first -- two more instructions -- for signalling NaNs)
+DEVFN double dmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 DEVFN double row16_max_f64(double x)  // every lane gets the maximum of its row (no NaNs here: comparisons and v_max agree)
 {
     auto rot = [](double v, auto ctrl) {
@@ -130,8 +137,8 @@ DEVFN double row16_max_f64(double x)  // every lane gets the maximum of its row 
         const int lo = dpp_row<decltype(ctrl)::value>((int)b), hi = dpp_row<decltype(ctrl)::value>((int)(b >> 32));
         return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
     };
-    x = fmax(x, rot(x, std::integral_constant<int, 0x121>{})); x = fmax(x, rot(x, std::integral_constant<int, 0x122>{}));
-    x = fmax(x, rot(x, std::integral_constant<int, 0x124>{})); x = fmax(x, rot(x, std::integral_constant<int, 0x128>{}));
+    x = dmax(x, rot(x, std::integral_constant<int, 0x121>{})); x = dmax(x, rot(x, std::integral_constant<int, 0x122>{}));
+    x = dmax(x, rot(x, std::integral_constant<int, 0x124>{})); x = dmax(x, rot(x, std::integral_constant<int, 0x128>{}));
     return x;
 }
 DEVFN double wave_sum_f64(double x)   // sum over the 64 lanes of the wave (all active): rows by DPP, then the four row sums

@@ -79,6 +79,7 @@ struct SharedCore {
     int si[NP][8];                // active, has_req, nues, buffer_size, buffer_latency, message_size, nparams, sorted
     int pi[NP][6];                // (metric, op) x 3
     int cnt[NP][NP + 4];          // RBs of each slot (padded like rows)
+    int acc[NP];                      // per slice: sum of the intra-slice floors (LDS atomic adds by the slice's UEs; zero between two allocations)
     unsigned msk[NP][2];              // per slice, one bit per UE position, set with LDS atomic ORs by the slice's UEs and read as ONE word:
                                       // [0] the UE's buffer is not empty, [1] its PF / MT value is non-zero.  All zero between two allocations
     int rbs[GRP], off[GRP];       // RBs of each slice and its first RB
@@ -250,8 +251,13 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             int extra = 0;
             if (nzf && adj > 0) {
                 int rank = 0;
+                if (__builtin_amdgcn_ballot_w64(my_v < 0.0) == 0) {       // (scores inside [-1, 1]: no negative value; see the intra-slice loop)
 #pragma unroll
-                for (int j = 0; j < NP; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
+                    for (int j = 0; j < NP; j++) { const double xj = xs[3][j]; rank += (j > s1 ? xj >= my_v : xj > my_v) ? 1 : 0; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NP; j++) { const double xj = xs[3][j]; rank += (xj != 0.0 && (xj > my_v || (xj == my_v && j > s1))) ? 1 : 0; }
+                }
                 // the floors leave fewer than m_nz units over unless rounding interferes: the integer division (~50 vector
                 // instructions with its remainder) only where some lane needs it
                 extra = rank < adj ? 1 : 0;
@@ -291,9 +297,10 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             const bool starved = d_isclose(snt, 0.0);
             double max_avail = 0.0;
             if (__builtin_amdgcn_ballot_w64(starved) != 0) {       // the slice maximum is only read by UEs that sent nothing
+                // (np.max over the slice's n entries: the row is zero beyond them and no entry is negative, so the maximum over all NP is the same)
                 max_avail = r0[0];
 #pragma unroll
-                for (int k = 1; k < NP; k++) { const double av = r0[k]; max_avail = (k < n && av > max_avail) ? av : max_avail; }
+                for (int k = 1; k < NP; k++) max_avail = dmax(max_avail, r0[k]);
             }
             num = starved ? 2.0 * max_avail : ddiv(avail, snt);
         }
@@ -317,20 +324,26 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
         }
     }
     if (!all_rr) {
-        if (have) sh.cnt[sl][pos] = prop;
+        // the slice's sum of the floors: one LDS atomic add per UE and one read (was: a row of ten floors, read back by every UE)
+        if (have && prop != 0) atomicAdd(&sh.acc[sl], prop);
         wg_sync(narrow);
     }
     int count = 0;
     if (use_round) {
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < NP; k++) acc += sh.cnt[sl][k];
-        const int adj = n_rbs - acc;
+        const int adj = n_rbs - sh.acc[sl];
         count = prop;
         if (nzv && adj > 0) {
+            // how many of the slice's non-zero values come before this one in np.argsort(values)[::-1] (stable: among equals the higher
+            // position first).  Values are positive unless the caller's SE tiles are negative: then a value that is greater or equal is
+            // non-zero by itself and the test for zero drops out (one wave-uniform look decides which loop runs)
             int rank = 0;
+            if (__builtin_amdgcn_ballot_w64(my_val < 0.0) == 0) {
 #pragma unroll
-            for (int k = 0; k < NP; k++) { const double xk = r2[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+                for (int k = 0; k < NP; k++) { const double xk = r2[k]; rank += (k > pos ? xk >= my_val : xk > my_val) ? 1 : 0; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; k++) { const double xk = r2[k]; rank += (xk != 0.0 && (xk > my_val || (xk == my_val && k > pos))) ? 1 : 0; }
+            }
             int more = rank < adj ? 1 : 0;
             if (__builtin_amdgcn_ballot_w64(adj >= m_v) != 0 && adj >= m_v) more = adj / m_v + (rank < adj % m_v ? 1 : 0);      // (as above)
             count += more;
@@ -347,13 +360,12 @@ DEVFN void alloc_front(const P &p, SharedCore<NP> &sh, int tid, int e, int hlen,
             count = (int)(each + ((unsigned)idx < rem ? 1u : 0u));
         }
     }
-    if (!all_rr) wg_sync(narrow);                                                  // every prop was read
     if (have) sh.cnt[sl][pos] = count;
     wg_sync(narrow);
-    if (have && pos == 0) { sh.msk[sl][0] = 0u; sh.msk[sl][1] = 0u; }              // (both masks were read in front of that barrier; the next ORs are barriers away)
+    if (have && pos == 0) { sh.msk[sl][0] = 0u; sh.msk[sl][1] = 0u; sh.acc[sl] = 0; }   // (masks and sum were read in front of that barrier; the next ORs / adds are barriers away)
     int before = 0;                                                                // :464-478 contiguous ranges
 #pragma unroll
-    for (int k = 0; k < NP; k++) before += k < pos ? sh.cnt[sl][k] : 0;
+    for (int k = 0; k < NP; k++) before += (int)((below >> k) & 1u) * sh.cnt[sl][k];   // (bit k of `below`: k < pos)
     rb_start = have ? off + before : 0;
     rb_count = have ? count : 0;
 }
@@ -601,6 +613,7 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
         }
         for (int i = tid; i < S * NP; i += LW) { const int sl0 = i / NP, j0 = i - sl0 * NP; sh.cnt[sl0][j0] = 0; }
         if (tid < S * 2) (&sh.msk[0][0])[tid] = 0u;
+        if (tid < S) sh.acc[tid] = 0;
         if (tid < S * 8) (&sh.si[0][0])[tid] = st_si0;
         if (tid + LW < S * 8) (&sh.si[0][0])[tid + LW] = st_si1;
         if (tid < S * 6) (&sh.pi[0][0])[tid] = st_pi0;

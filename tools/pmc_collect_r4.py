@@ -1,6 +1,6 @@
 """rocprofv3 --pmc passes -> profiles/r04_pmc.json.
 
-    python tools/pmc_collect_r4.py <out.json> <batch> <config> <entry>:<ttis>:<dir>[,<dir>...] ...
+    python tools/pmc_collect_r4.py <out.json> <batch> <config> <entry>:<ttis>:<dir>[,<dir>...][:<batch>:<config>] ...
 
 An entry is one (schedule, SE mode): `stream_rollout`, `gather_rollout` (tools/profile_rollout.py: the headline's compact, fused
 rollouts over 3 partitions; <ttis> = the TTIs of the whole batch that process stepped, printed by the driver) or `stream`, `gather`
@@ -30,15 +30,18 @@ res = {"batch": batch, "config": config, "date": datetime.date.today().isoformat
                "stepped; FETCH_SIZE doubled per the gfx950 correction; counter passes serialise launches (times do not stand, "
                "bytes and instructions do)"}
 for spec in sys.argv[4:]:
-    entry, ttis, ds = spec.split(":", 2)
+    fields = spec.split(":")
+    entry, ttis, ds = fields[0], fields[1], fields[2]
     ttis, dirs = float(ttis), ds.split(",")
     m = {"ttis": ttis}
+    if len(fields) > 4:            # a block of another workload: entry:ttis:dirs:batch:config
+        m.update({"batch": int(fields[3]), "config": int(fields[4])})
     fetch, nf = summed(dirs, "FETCH_SIZE")
     write, nw = summed(dirs, "WRITE_SIZE")
     if fetch is not None and write is not None:
         m.update({"fetch_size_kib_raw_per_tti": fetch / ttis, "write_size_kib_per_tti": write / ttis,
                   "hbm_bytes_per_tti": (2.0 * fetch + write) * 1024.0 / ttis, "launches": min(nf, nw),
-                  "ttis_per_launch_and_partition": ttis * 3 / max(1, min(nf, nw)) if "rollout" in entry and batch >= 2048 else ttis / max(1, min(nf, nw))})
+                  "ttis_per_launch_and_partition": ttis * 3 / max(1, min(nf, nw)) if "rollout" in entry and m.get("batch", batch) >= 2048 else ttis / max(1, min(nf, nw))})
         m["hbm_bytes_per_launch"] = m["hbm_bytes_per_tti"]          # (the key bench.py's round-3 reader used: per TTI of the batch)
     for ctr, key in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_SALU", "salu_insts"), ("SQ_WAVES", "waves"),
                      ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu"),
