@@ -462,6 +462,16 @@ int ranenv_get_option(ranenv_handle h, const char *key, int64_t *value);
  * rows, the traffic pool, the sidecar of per-tile means -- must stay below 4 GB.  1 = yes, 0 = no (one env per wave), < 0 = error. */
 int ranenv_packed_step_fits(const ranenv_config *cfg, int64_t traffic_rows, int64_t se_tiles);
 
+/* Self-test of the kernels' division.  The step kernels divide doubles with the compiler's correctly rounded sequence WITHOUT its three guard
+ * instructions (v_div_scale x 2, v_div_fixup) wherever the divisor is a positive normal number of moderate magnitude whenever the result is
+ * used -- packet sizes, counts, sums, the validated normalisers; explicit traffic (the caller's doubles) goes through the plain operator.
+ * This entry point runs both forms inside the SHIPPED build on the caller's operands (device pointers, n elements): fast[i] = the guard-free
+ * sequence, ieee[i] = a[i] / b[i].  They are bit-identical for a = 0 or a in [2^-900, 2^900], b in [1e-30, 1e30] and a quotient in
+ * [2^-900, 2^900] (tests/test_gpu_flags_and_errors.py: the kernels' operands -- counts, sizes, sums of 1e-9 ... 1e12 -- and the edges of that
+ * domain); outside it -- b zero, denormal, infinite or NaN, or operands so small that the correction step's residual is a denormal -- only
+ * ieee is defined.  No handle (errors: ranenv_last_error(NULL)). */
+int ranenv_selftest_ddiv(const double *dev_a, const double *dev_b, double *dev_fast, double *dev_ieee, int64_t n, void *stream);
+
 /* Last launch geometry (for roofline accounting): grid blocks, block threads, LDS bytes. */
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes);
 

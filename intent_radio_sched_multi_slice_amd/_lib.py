@@ -27,7 +27,7 @@ EXPORTS = (
     "ranenv_autoreset", "ranenv_get_poisson_tables", "ranenv_set_partitions", "ranenv_rollout", "ranenv_enable_metrics", "ranenv_get_metrics",
     "ranenv_step_range", "ranenv_set_se_mode", "ranenv_get_se_sidecars", "ranenv_step_part", "ranenv_wait_part",
     "ranenv_get_partition", "ranenv_get_part_stream", "ranenv_autoreset_part", "ranenv_set_option", "ranenv_get_option", "ranenv_profile_work", "ranenv_bind_se_gather_from_power",
-    "ranenv_bind_se_pool_quad", "ranenv_se_retile_quad", "ranenv_packed_step_fits",
+    "ranenv_bind_se_pool_quad", "ranenv_se_retile_quad", "ranenv_packed_step_fits", "ranenv_selftest_ddiv",
 )
 
 
@@ -140,6 +140,7 @@ def load() -> C.CDLL:
     lib.ranenv_autoreset_part.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
     lib.ranenv_bind_se_gather_from_power.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p]
     lib.ranenv_profile_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.ranenv_selftest_ddiv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ranenv_packed_step_fits.argtypes = [C.POINTER(Config), C.c_int64, C.c_int64]
     lib.ranenv_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.ranenv_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]

@@ -383,9 +383,26 @@ __global__ void __launch_bounds__(256) ranenv_idle_traffic_kernel(const ranenv_e
     if (bad) atomicOr(violations, 1);
 }
 
+// ddiv() against the compiler's IEEE division on caller-supplied operands (ranenv_selftest_ddiv: the parity check of the guard-free
+// sequence inside the shipped build -- no second build with RANENV_FAST_DIV=0 needed)
+__global__ void __launch_bounds__(256) ranenv_ddiv_selftest_kernel(const double *a, const double *b, double *fast, double *ieee, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        fast[i] = ddiv(a[i], b[i]);
+        ieee[i] = a[i] / b[i];
+    }
+}
+
 }  // namespace
 
 namespace ranenv_dev {
+
+void launch_ddiv_selftest(hipStream_t s, const double *a, const double *b, double *fast, double *ieee, long long n)
+{
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ranenv_ddiv_selftest_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, a, b, fast, ieee, n);
+}
 
 void launch_classify(hipStream_t s, const ranenv_episode *eps, const int32_t *members, int B, int n_class, int one_class, int32_t *list,
                      int32_t *count, int *flag, int force)

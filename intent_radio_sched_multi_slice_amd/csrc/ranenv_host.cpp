@@ -1749,6 +1749,17 @@ int ranenv_packed_step_fits(const ranenv_config *cfg, int64_t traffic_rows, int6
     return pack_fits_32_of(*cfg, (long long)traffic_rows, (long long)se_tiles) ? 1 : 0;
 }
 
+int ranenv_selftest_ddiv(const double *dev_a, const double *dev_b, double *dev_fast, double *dev_ieee, int64_t n, void *stream)
+{
+    if (!dev_a || !dev_b || !dev_fast || !dev_ieee) return fail(nullptr, RANENV_E_INVALID, "null argument");
+    if (n < 0) return fail(nullptr, RANENV_E_INVALID, "negative element count");
+    if (n == 0) return RANENV_OK;
+    launch_ddiv_selftest((hipStream_t)stream, dev_a, dev_b, dev_fast, dev_ieee, (long long)n);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, RANENV_E_HIP, "ddiv self-test launch: %s", hipGetErrorString(e));
+    return RANENV_OK;
+}
+
 int ranenv_launch_info(ranenv_handle h, int32_t *grid, int32_t *block, int32_t *lds_bytes)
 {
     if (!h) return fail(h, RANENV_E_INVALID, "null handle");

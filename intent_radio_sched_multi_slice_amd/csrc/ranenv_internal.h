@@ -222,6 +222,7 @@ void launch_se_sidecar_from_power(hipStream_t, unsigned n_tiles, unsigned block,
                                   double tx, double noise, double *mean, float *um);
 void launch_se_retile_quad(hipStream_t, unsigned blocks, const float *src, float *dst, long long n_quads, int U, int R);
 void launch_se_from_power(hipStream_t, unsigned blocks, const double *power, float *se, long long n, double tx_per_rb, double noise);
+void launch_ddiv_selftest(hipStream_t, const double *a, const double *b, double *fast, double *ieee, long long n);
 void launch_head(hipStream_t, dim3 grid, dim3 block, const KP &);
 void launch_advance(hipStream_t, unsigned n_envs, const AdvanceArgs &);
 void launch_idle_traffic(hipStream_t, unsigned n_eps, const ranenv_episode *eps, const int32_t *pool, int U, const int32_t *lane_slice,

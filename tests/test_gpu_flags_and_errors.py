@@ -743,3 +743,48 @@ def test_masked_reset_after_a_persistent_abort_does_not_leave_a_stale_step_shado
     moved = b.views()["episode_number"] != ep0
     assert torch.equal(moved, n_resets > 0) or n_ep == 1
     a.close(); b.close()
+
+
+def test_guard_free_division_equals_ieee_division_on_the_kernels_operand_domain():
+    """ddiv() -- the compiler's f64 division without v_div_scale / v_div_fixup -- must give the bits of the plain operator wherever the
+    kernels use it: divisors that are positive normal numbers (packet sizes, UE / RB / slice counts, window lengths, 1e6, sums of weights, the
+    validated normalisers in [1e-30, 1e30]), dividends that are finite and >= 0.  Checked inside the shipped build (ranenv_selftest_ddiv) on
+    random and edge operands; explicit traffic -- the one caller-supplied dividend that may be inf / huge -- does not go through ddiv at all."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from intent_radio_sched_multi_slice_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    a = np.concatenate([
+        rng.integers(0, 2 ** 31, n).astype(np.float64),                          # packet / bit counts
+        rng.random(n) * 10.0 ** rng.integers(-9, 13, n),                         # sums, rates, weights: 1e-9 ... 1e12
+        np.array([0.0, 1.0, 2.0 ** -900, 2.0 ** 900, 1e-250, 1e250, 135.0, 1e8, 1e6, 2.0 ** -899, np.nextafter(1.0, 2.0), 2.0 ** 52 + 1.0]),
+    ])
+    b = np.concatenate([
+        rng.integers(1, 2 ** 20, n).astype(np.float64),                          # integer divisors: sizes, counts
+        rng.random(n) * 10.0 ** rng.integers(-9, 13, n) + 1e-12,
+        np.array([1.0, 3.0, 1e6, 135.0, 7.0, 1e-30, 1e30, 2.0 ** -100, 2.0 ** 100, 640.0, np.nextafter(1.0, 0.0), 3.0]),
+    ])
+    # (the domain: dividend 0 or in [2^-900, 2^900] -- below that the residual of the correction step is a denormal and the last bit can differ,
+    # which is what v_div_scale is for; the kernels' dividends are counts and sums of 1e-9 ... 1e12 -- and a quotient in the same range)
+    # every pairing of the edge dividends with the edge divisors whose quotient stays in that range
+    ea, eb = np.meshgrid(a[-12:], b[-12:])
+    ea, eb = ea.ravel(), eb.ravel()
+    with np.errstate(over="ignore", under="ignore"):
+        q = ea / eb
+    ok = (q == 0.0) | ((np.abs(q) >= 2.0 ** -900) & (np.abs(q) <= 2.0 ** 900))
+    a, b = np.concatenate([a[:-12], ea[ok]]), np.concatenate([b[:-12], eb[ok]])
+    ta, tb = torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev)
+    fast, ieee = torch.empty_like(ta), torch.empty_like(ta)
+    st = lib.ranenv_selftest_ddiv(C.c_void_p(ta.data_ptr()), C.c_void_p(tb.data_ptr()), C.c_void_p(fast.data_ptr()), C.c_void_p(ieee.data_ptr()),
+                                  ta.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert st == 0
+    torch.cuda.synchronize()
+    f, i = fast.cpu().numpy(), ieee.cpu().numpy()
+    with np.errstate(over="ignore", under="ignore"):
+        assert np.array_equal(i.view(np.uint64), (a / b).view(np.uint64))      # the device's IEEE division is numpy's
+    bad = np.flatnonzero(f.view(np.uint64) != i.view(np.uint64))
+    assert bad.size == 0, [(a[k], b[k], f[k], i[k]) for k in bad[:5]]

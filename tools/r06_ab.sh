@@ -26,7 +26,8 @@ for spec in sys.argv[2:]:
         hs, gs, ss, ps = [], [], [], []
         for f in sorted(glob.glob(f"{out}/{n}_K{K}_r*.json")):
             try:
-                d = json.loads(open(f).read().strip().splitlines()[-1]); hs.append(d["ms_per_step"] * 1e3); gs.append(d["se_gather"]["ms_per_step"] * 1e3)
+                d = json.loads(open(f).read().strip().splitlines()[-1]); hs.append(d["ms_per_step"] * 1e3)
+                if "ms_per_step" in d.get("se_gather", {}): gs.append(d["se_gather"]["ms_per_step"] * 1e3)
                 if "single_stream" in d: ss.append(d["single_stream"]["ms_per_step"] * 1e3); ps.append(d["pipelined_step"]["ms_per_step"] * 1e3)
             except Exception as e: print("bad", f, e)
         row.append(f"K={K}: stream " + " ".join(f"{x:.2f}" for x in hs) + "  gather " + " ".join(f"{x:.2f}" for x in gs)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The GPU suite under the experiment knobs (every option changes a schedule or a build, never a result).
-tag=${1:-r05knobs}
+tag=${1:-r06knobs}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -12,8 +12,7 @@ run() {  # name env...
 }
 run compact0 RANENV_COMPACT=0
 run row16 RANENV_ROW_WIDTH=16
-run late2 RANENV_LATE=2
-run late1_fuse3 RANENV_LATE=1 RANENV_FUSE=3
+run fuse3 RANENV_FUSE=3
 run fuse1 RANENV_FUSE=1
 run fuse20 RANENV_FUSE=20
 run small0 RANENV_SMALL_BATCH=0
@@ -23,4 +22,5 @@ run gather_row16_fuse20_compact0 RANENV_SE_MODE=gather RANENV_ROW_WIDTH=16 RANEN
 run persist_handover_stress RANENV_PERSIST=1 RANENV_PERSIST_GRID=64 RANENV_PERSIST_CHUNK=1
 run rbmajor_persist1 RANENV_SE_LAYOUT=rb RANENV_PERSIST=1
 run rbmajor_gather RANENV_SE_LAYOUT=rb RANENV_SE_MODE=gather
+run shortcut0 RANENV_AUTORESET_SHORTCUT=0
 echo "pass complete"

@@ -1,10 +1,11 @@
 #!/bin/bash
 # VALU wave-instructions per TTI by role: SQ_INSTS_VALU of the full build and of the ablation builds (-DRANENV_DIAG=3 no UE step, 4 no observation
 # tail, 7 no allocation, 11 no masked half of the stream), launch-per-chunk rollouts (RANENV_PERSIST=0), both SE modes
-out=$1; V=intent_radio_sched_multi_slice_amd/csrc/variants; mkdir -p $out; export TMPDIR=/tmp
+# The ablation builds are made in the build container first: tools/build_variants.sh diag3:-DRANENV_DIAG=3 diag4:-DRANENV_DIAG=4 diag7:-DRANENV_DIAG=7 diag11:-DRANENV_DIAG=11
+out=$1; V=tools/variants; mkdir -p $out; export TMPDIR=/tmp
 for mode in stream gather; do
 for v in full diag3 diag4 diag7 diag11; do
-  lib=$V/lib_$v.so; [ $v = full ] && lib=intent_radio_sched_multi_slice_amd/csrc/libranenv_hip.so
+  lib=$V/$v.so; [ $v = full ] && lib=intent_radio_sched_multi_slice_amd/csrc/libranenv_hip.so
   RANENV_LIB=$lib RANENV_PERSIST=0 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $out/${mode}_$v -o p --output-format csv -- python3 tools/profile_rollout.py 50 2 $mode > $out/${mode}_$v.log 2>&1 || { echo "failed $mode $v"; tail -3 $out/${mode}_$v.log; }
 done; done
 python3 - $out <<'PY'
