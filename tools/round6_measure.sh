@@ -1,7 +1,7 @@
 #!/bin/bash
 # One measurement pass on the GPU box (round 6): parity tests, bench lines, PMC passes of the schedules bench.py times (headline, gather,
 # native size, configs[1]), rocprofv3 kernel stats, the K = 20 block and the trainer-facing schedules' timelines.
-# Usage (through gpurun): bash tools/round6_measure.sh <tag> [skip_pytest] [part]   -> gpurun_out/<tag>/      part: all (default) | bench | pmc | prof
+# Usage (through gpurun): bash tools/round6_measure.sh <tag> [skip_pytest] [part]   -> gpurun_out/<tag>/      part: all (default: bench + pmc + prof) | bench | pmc | prof | phases
 set -o pipefail
 tag=${1:-r06}; part=${3:-all}
 out=gpurun_out/$tag
@@ -51,5 +51,11 @@ step prof_gather 400 rocprofv3 --kernel-trace --stats -d $out/prof_gather -o p -
 step prof_steploop 400 rocprofv3 --kernel-trace -d $out/prof_steploop -o p --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gather --no-other-configs
 python3 tools/steploop_timeline.py $out/prof_steploop/p_kernel_trace.csv 20 > $out/steploop_timeline.txt 2>&1 || python3 tools/steploop_timeline.py $(ls $out/prof_steploop/*/p_kernel_trace.csv | head -1) 20 > $out/steploop_timeline.txt 2>&1
 cat $out/steploop_timeline.txt
+fi
+if [ $part = phases ]; then      # (needs tools/variants/diag{3,4,7,11,12}.so: tools/build_variants.sh in the build container)
+RANENV_LIB=$PWD/tools/variants/diag12.so RANENV_PERSIST=1 step phases_stream 300 python3 tools/persist_phases.py 2 200
+RANENV_LIB=$PWD/tools/variants/diag12.so step phases_gather 300 python3 tools/persist_phases.py 2 200 gather
+RANENV_LIB=$PWD/tools/variants/diag12.so step phases_config1 300 python3 tools/persist_phases.py 1 200
+TAILN=12 step valu_phases 1200 bash tools/valu_phases.sh $out/valu_phases
 fi
 echo "pass complete"
