@@ -191,9 +191,10 @@ def build_line(args, world, batch, label, env_sizes, alg_bytes_env_step, times, 
     env_ttis_per_launch = kms.get("n_env_ttis", batch / parts * kms.get("n_ttis", n_launches)) / max(1, n_launches)
     launch_bytes = alg_bytes_env_step * env_ttis_per_launch                   # algorithmic bytes of the average launch
     launch_gbs = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    traffic = (pmc or {}).get("stream_rollout" if (parts > 1 or persistent) else "stream")
+    mode = "gather" if getattr(args, "only_gather", False) else "stream"
+    traffic = (pmc or {}).get(f"{mode}_rollout" if (parts > 1 or persistent) else mode)
     moved_per_tti = traffic.get("hbm_bytes_per_tti") if traffic else None      # HBM bytes one TTI of the whole batch moves (counters)
-    kname = "ranenv_persist_kernel<stream>" if persistent else "ranenv_core_kernel<STEP>"
+    kname = f"ranenv_persist_kernel<{mode}>" if persistent else ("ranenv_core_kernel_gather<STEP>" if mode == "gather" else "ranenv_core_kernel<STEP>")
     if persistent:
         schedule = (f"ranenv_rollout as a persistent work-queue launch (option persist, auto): the K TTIs of the device policy in ONE "
                     f"launch per workgroup class ({n_launches} launch(es) for the timed call: envs sorted by the waves a compact step "
