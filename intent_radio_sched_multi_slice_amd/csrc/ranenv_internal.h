@@ -13,7 +13,7 @@
 
 #ifndef RANENV_DIAG
 #define RANENV_DIAG 0   /* diagnostic builds only (tools/build_variants.sh; see the table in DESIGN.md section 8): 3 / 4 / 7 / 11 skip the UE step / the
-                           observation tail / the allocation / the masked half of the stream (tools/r05_valu_phases.sh counts instructions by difference),
+                           observation tail / the allocation / the masked half of the stream (tools/valu_phases.sh counts instructions by difference),
                            9 / 12 stamp s_memtime at the phase boundaries of the one-TTI / the persistent launches (tools/stamps.py, persist_phases.py) */
 #endif
 

@@ -3,7 +3,7 @@
     python tools/persist_phases.py <config: 1 | 2 | 4 | native> <K> [gather]
 Phases: gap = between two TTIs of a chunk (barrier + loop); 1 entry (loads requested, tables parked, first barrier); 2 allocation;
 3 SE stream / gather (+ the rest of the state in the builds that request it there); 4 barrier; 5 UE step; 6 barrier;
-7 observation tail; 8 allocation ahead / hand-over."""
+7 observation tail; 8 tail / hand-over."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
