@@ -113,3 +113,31 @@ def test_bad_quad_pool_arguments_are_refused():
     with pytest.raises(_lib.RanEnvError):
         env.bind_se_pool(torch.zeros((3, 5, 10, 4), dtype=torch.float32, device=env.device))
     env.close()
+
+
+def test_one_pool_copy_is_shared_zero_copy_between_workloads():
+    """bench.py keeps ONE copy of the SE pool: a workload built with keep_rb_major=False hands out the RB-quad-major tensor that is
+    bound (the RB-major tensor the generator wrote is dropped), a second workload binds that very tensor without copying, and both replay the
+    same tiles as a workload that kept the RB-major pool."""
+    _need_gpu()
+    from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
+    dev = torch.device("cuda", 0)
+    ref = make_mult_slice_workload(32, dev, n_scenarios=4, n_traces=3, trace_len=7)                      # keeps the RB-major tensor
+    a = make_mult_slice_workload(32, dev, n_scenarios=4, n_traces=3, trace_len=7, keep_rb_major=False)
+    assert a.se_pool.dim() == 4 and a.se_pool is a.env.bound_se_pool and a.env.se_pool_rb_major is None
+    b = make_mult_slice_workload(32, dev, n_scenarios=4, n_traces=3, trace_len=7, se_pool=a.se_pool)     # binds the quad tensor as it is
+    assert b.env.bound_se_pool.data_ptr() == a.se_pool.data_ptr() and b.env.se_layout == "quad"
+    idx = torch.arange(21, device=dev)
+    assert torch.equal(a.env.pooled_tiles(idx), ref.se_pool) and torch.equal(b.env.pooled_tiles(idx), ref.se_pool)
+    outs = []
+    for wl in (ref, a, b):
+        wl.env.reset(); wl.env.rollout(11); torch.cuda.synchronize()
+        v = wl.env.views()
+        outs.append((wl.env.reward.clone(), wl.env.obs_inter.clone(), v["queue_pkts"].clone(), v["pkt_throughputs"].clone()))
+    for x, y, z in zip(*outs):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    kept = make_mult_slice_workload(8, dev, n_scenarios=4, n_traces=3, trace_len=7)
+    kept.env.bind_se_pool(kept.se_pool, keep_rb_major=True)
+    assert kept.env.se_pool_rb_major is kept.se_pool
+    for wl in (ref, a, b, kept):
+        wl.env.close()
