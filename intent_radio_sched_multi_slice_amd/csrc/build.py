@@ -77,4 +77,10 @@ if __name__ == "__main__":
     out = OUT
     if "-o" in args:
         out = os.path.abspath(args[args.index("-o") + 1])
-    print(build(force="--force" in args or out != OUT, verbose=True, out=out, defines=tuple(a for a in args if a.startswith("-D"))))
+    extra = []
+    for a in args:                 # -DNAME=value, and for compiler experiments: -X<flag> passes <flag> on (-X-mllvm -X-some-option)
+        if a.startswith("-D"):
+            extra.append(a)
+        elif a.startswith("-X"):
+            extra.append(a[2:])
+    print(build(force="--force" in args or out != OUT, verbose=True, out=out, defines=tuple(extra)))
