@@ -13,6 +13,7 @@ import os
 import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,7 +51,8 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=()
     if not force and not is_stale(out):
         return out
     hipcc = hipcc_path()
-    objdir = os.path.join(HERE, "_obj", os.path.basename(out))
+    # (objects of the shipped library stay in-tree beside it; a variant's objects are scratch)
+    objdir = os.path.join(HERE, "_obj") if out == OUT else tempfile.mkdtemp(prefix="ranenv_obj_")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_unit(unit):
@@ -69,6 +71,8 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=()
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(out + ".tmp", out)
+    if out != OUT:
+        shutil.rmtree(objdir, ignore_errors=True)
     return out
 
 
