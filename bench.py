@@ -366,6 +366,9 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="plumbing rehearsal of a multi-rank launch on a box with ONE GPU: every rank uses cuda:0 and the process "
                          "group is gloo (RCCL refuses two ranks on one device); the line is labelled a rehearsal, not a measurement")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal aid: at N = 1 initialise the RCCL process group anyway and send the clock's MAX, the barrier and the metrics gather "
+                         "through it (communicator creation and the three collectives of the multi-rank path on ONE rank)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the plain command: this process only starts the ranks (one per GPU) and relays rank 0's line; nothing here has
@@ -390,8 +393,10 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible: one rank per GPU")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -417,14 +422,14 @@ def main():
     coll_dev = torch.device("cpu") if args.rehearse_on_one_gpu else device       # gloo reduces host tensors
 
     def max_over_ranks(x):
-        if world == 1:
+        if not use_dist:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     gm = (lambda v: gather_metrics(v.cpu())) if args.rehearse_on_one_gpu else gather_metrics
-    barrier = dist.barrier if world > 1 else (lambda: None)
+    barrier = dist.barrier if use_dist else (lambda: None)
     sync = torch.cuda.synchronize
     K = args.steps
     extras = {}
@@ -450,7 +455,7 @@ def main():
         times, kms = rollout_variant()
         # metrics: the only collective, once per reporting interval, outside the timed K steps ...
         gathered = gm(local_metrics(env.reward, env.views(), env.done, K))
-        if world > 1:
+        if use_dist:
             # what the collective itself saw, and every GPU's own clock (its median block up to its own device sync)
             alg_tti = env.algorithmic_bytes_per_env_step("stream") * batch
             mine = torch.tensor([kms["local_block_s"]], dtype=torch.float64, device=device)
@@ -461,7 +466,7 @@ def main():
                                  "roofline_frac": [alg_tti * K / t / (HBM_PEAK_GBS * 1e9) for t in per_rank_s],
                                  "note": "every rank's own median block of K steps up to its own device sync (before the closing "
                                          "barrier), gathered with the metrics collective; roofline.frac above uses the MAX-over-ranks clock"}
-        if world > 1:     # ... and one variant with it inside: K steps + the all_gather of the interval's accumulators
+        if use_dist:      # ... and one variant with it inside: K steps + the all_gather of the interval's accumulators
             tg = timed_blocks(lambda: (env.rollout(K), gm(local_metrics(env.reward, env.views(), env.done, K))),
                               sync, barrier, max_over_ranks)
             extras["with_metrics_gather"] = dict(block_stats(tg, batch * world * K, K),
@@ -583,7 +588,7 @@ def main():
             except Exception:
                 pass
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -44,7 +44,7 @@ def local_metrics(reward: torch.Tensor, views: Dict[str, torch.Tensor], done: to
 
 def gather_metrics(vec: torch.Tensor) -> torch.Tensor:
     """[world, len(vec)] on every rank; identity (1 row) without an initialised process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return vec[None, :].clone()
     out: List[torch.Tensor] = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
     dist.all_gather(out, vec)
