@@ -100,6 +100,9 @@ class BatchedRanEnv:
         self.term_obs_inter = self.term_obs_intra = self.term_head_obs = None
         self.se_mode = "stream"
         self._ranges = None          # set_ranges(): [(lo, hi)] for step_async / step_wait
+        # (the views are handed out once, here: ranenv_get_views ends the library's host shadow of the step counters -- the views are writable --,
+        # and a first views() call in the middle of an auto-reset loop would switch the shortcut of enable_autoreset off until the next full reset)
+        self.views()
 
     # ------------------------------------------------------------------------------------------
     def close(self):
