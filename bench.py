@@ -439,6 +439,8 @@ def main():
         env.set_partitions(parts)
         env.reset()
         env.rollout(max(1, args.warmup))
+        # (the timed schedule itself is warmed by timed_blocks: its first block of K steps -- same call, same launches, class lists and queues of the
+        # persistent rollout already built -- only sizes the sample and is not among the blocks `value` is the median of)
         local = []
         times = timed_blocks(lambda: env.rollout(K), sync, barrier, max_over_ranks, local_out=local)
         env.profile_begin()
