@@ -503,6 +503,131 @@ DEVFN double gather_part(const float *tile, int tile_bytes, int row_bytes_off, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same masked sum with the loads SPREAD over the wave's lanes (round 6).  Only ~16 of an env's UEs get RBs at a TTI, and the one
+// with the most walks 5-6 groups one memory round trip after the other while the other lanes wait: gather_part's phase is ~4.5 dependent
+// round trips per TTI (tools/rb_range_stats.py).  Here every (owner lane, 8-RB group) pair that gather_part would load is a work item;
+// the items of the wave (~33 at the headline size: every RB belongs to one UE) are numbered by a wave scan, item i is loaded and masked by
+// LANE i -- all of them in ONE round trip --, and the owners then add their items' eight values in group order, fetched from the helper
+// lanes by ds_bpermute (the LDS crossbar, no memory).  The additions, their order, the tree per leaf, the sequential tail and the folding of
+// the leaves are gather_part's: bit for bit the same sum.  `desc`: 64 16-bit item descriptors of this wave in LDS (owner lane | group << 6 |
+// tail << 12).  Returns false -- nothing done -- when the wave has more than 63 items (lane 63 must stay a lane of zeros): the caller falls
+// back to gather_part.
+// ---------------------------------------------------------------------------------------------
+DEVFN int wave_excl_scan_i32(int x, int &total)      // exclusive prefix sum over the 64 lanes (all active); total = the wave's sum
+{
+    const int incl = row16_scan(x);                  // within the 16-lane rows
+    const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47),
+              t3 = __builtin_amdgcn_readlane(incl, 63);
+    const int row = (int)(threadIdx.x & 63u) >> 4;
+    const int before = (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+    total = t0 + t1 + t2 + t3;
+    return incl - x + before;
+}
+DEVFN double bperm_f64(double v, int src_lane)       // lane src_lane's v (every lane executes this)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)b), hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <bool PE>
+DEVFN bool gather_part_spread(const float *tile, int tile_bytes, int row_bytes_off, int R, unsigned s, unsigned c, const double scale,
+                              unsigned short *desc, double &part)
+{
+    constexpr int OOB = 0x7ffffff0;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const RowPlan pl = make_row_plan(R);
+    const int tail = R & 7, lane = (int)(threadIdx.x & 63u);
+    auto leaf_len = [&](int k) { return (k == 0) * pl.len0 + (k == 1) * pl.len1 + (k == 2) * pl.len2 + (k == 3) * pl.len3; };
+    // this lane's groups inside leaf [base, base + len): first group (absolute index) and how many -- as gather_part counts them
+    auto my_groups = [&](int base, int len, int &g0, int &ng) {
+        const int end = base + (len & ~7);
+        const int lo = (int)s > base ? (int)s : base, hi = (int)(s + c) < end ? (int)(s + c) : end;
+        g0 = 0; ng = 0;
+        if (lo < hi) { g0 = lo >> 3; ng = ((hi - 1) >> 3) - g0 + 1; }
+    };
+    const int row_end = R & ~7;                                     // first RB of the row's tail group
+    const bool want_tail = tail > 0 && (int)(s + c) > row_end && c > 0;
+    // 1. count and number the items
+    int n_items = want_tail ? 1 : 0;
+    {
+        int base = 0;
+#pragma unroll 1
+        for (int k = 0; k < pl.n_leaves; k++) { int g0, ng; my_groups(base, leaf_len(k), g0, ng); n_items += ng; base += leaf_len(k); }
+    }
+    int total = 0;
+    const int off = wave_excl_scan_i32(n_items, total);
+    if (total > 63) return false;                                   // (wave-uniform)
+    // 2. the owners describe their items, in the order they will add them: leaf by leaf, groups ascending, the tail last
+    {
+        int base = 0, at = off;
+#pragma unroll 1
+        for (int k = 0; k < pl.n_leaves; k++) {
+            int g0, ng; my_groups(base, leaf_len(k), g0, ng);
+#pragma unroll 1
+            for (int m = 0; __builtin_amdgcn_ballot_w64(m < ng) != 0; m++)
+                if (m < ng) desc[at + m] = (unsigned short)(lane | ((g0 + m) << 6));
+            at += ng; base += leaf_len(k);
+        }
+        if (want_tail) desc[at] = (unsigned short)(lane | ((row_end >> 3) << 6) | (1 << 12));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (this wave's own area: an LDS wait, no barrier)
+    // 3. lane i loads and masks item i
+    double m[8];
+    {
+        const bool have = lane < total;
+        const int d = have ? (int)desc[lane] : 0;
+        const int owner = d & 63, gi = (d >> 6) & 63;
+        const unsigned os = (unsigned)__builtin_amdgcn_ds_bpermute(owner << 2, (int)s), oc = (unsigned)__builtin_amdgcn_ds_bpermute(owner << 2, (int)c);
+        const int orow = __builtin_amdgcn_ds_bpermute(owner << 2, row_bytes_off);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile), 0, tile_bytes, 0x00020000);
+        const int o = have ? orow + gi * 32 : OOB;
+        const v4f a = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, SE_AUX_NT));
+        const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o < OOB ? o + 16 : OOB, 0, SE_AUX_NT));
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const unsigned r0 = (unsigned)(gi * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool in = have && ((r0 + (unsigned)j - os) < oc);
+            // (the product with 0 / 1 and the sum with +0.0 are exact: the owner's `g + m` below is gather_part's fma(x, mask, g) bit for bit)
+            m[j] = fma(PE ? (double)x[j] * scale : (double)x[j], in ? 1.0 : 0.0, 0.0);
+        }
+    }
+    // 4. the owners add their items in order (a lane past its last item reads lane 63: zeros, since total <= 63)
+    double lg = 0.0, rg = 0.0;
+    int base = 0, at = off;
+#pragma unroll 1
+    for (int k = 0; k < pl.n_leaves; k++) {
+        int g0, ng; my_groups(base, leaf_len(k), g0, ng);
+        double g[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) g[j] = 0.0;
+#pragma unroll 1
+        for (int it = 0; __builtin_amdgcn_ballot_w64(it < ng) != 0; it++) {
+            const int src = it < ng ? at + it : 63;
+#pragma unroll
+            for (int j = 0; j < 8; j++) g[j] += bperm_f64(m[j], src);
+        }
+        double gr = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+        at += ng;
+        if (k == pl.n_leaves - 1 && tail > 0) {
+            if (__builtin_amdgcn_ballot_w64(want_tail) != 0) {
+                const int src = want_tail ? at : 63;
+#pragma unroll
+                for (int j = 0; j < 7; j++)
+                    if (j < tail) gr += bperm_f64(m[j], src);
+            }
+        }
+        const bool left = pl.lsplit ? (k < 2) : (k < 1);
+        const bool first_of_half = pl.lsplit ? (k == 0 || k == 2) : (k <= 1);
+        if (left) lg = first_of_half ? gr : lg + gr;
+        else      rg = first_of_half ? gr : rg + gr;
+        base += leaf_len(k);
+    }
+    part = pl.n_leaves == 1 ? lg : lg + rg;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Counter-based random numbers: Philox-4x32-10 (Salmon et al., SC'11).  One call = 128 random bits that depend
 // only on (key, counter): the exogenous inputs of an env never depend on what the agent did
 // (results/gen_results.py:1587-1635 checks exactly that across agents).

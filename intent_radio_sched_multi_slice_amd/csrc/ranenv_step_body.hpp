@@ -653,7 +653,16 @@ DEVFN bool step_body(const P &p, StepCarry &cy, const bool warm, const int e_in,
     double my_full = 0.0, my_part = 0.0;
     auto hook = []() {};
     if constexpr (GATHER) {
-        if (MODE == MODE_STEP) my_part = gather_part<PACK, GDEPTH, PE>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count, PE ? COLD(bw_per_rb) : 1.0);
+        if (MODE == MODE_STEP) {
+            bool spread = false;
+            if constexpr (PACK == 1) {
+                // (this wave's 64 item descriptors live in the cross-slice rows: free between the allocation and the observation tail, and every
+                // reader of those rows writes what it reads first)
+                unsigned short *desc = reinterpret_cast<unsigned short *>(&sh.xr[0][0]) + (narrow ? 0 : (tid >> 6)) * 64;
+                spread = gather_part_spread<PE>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count, PE ? COLD(bw_per_rb) : 1.0, desc, my_part);
+            }
+            if (!spread) my_part = gather_part<PACK, GDEPTH, PE>(tile, U * p.se_rp * 4, u * p.se_rp * 4, R, (unsigned)rb_start, (unsigned)rb_count, PE ? COLD(bw_per_rb) : 1.0);
+        }
     } else if constexpr (MODE == MODE_STEP) {
         const unsigned us1 = (unsigned)rb_start, uc1 = (unsigned)rb_count;
         row_sums<PE>(se1, R, [=](int r) { return ((unsigned)r - us1) < uc1; }, my_full, my_part, hook, PE ? COLD(bw_per_rb) : 1.0);
