@@ -115,11 +115,12 @@ def test_bad_quad_pool_arguments_are_refused():
     env.close()
 
 
-def test_one_pool_copy_is_shared_zero_copy_between_workloads():
+def test_one_pool_copy_is_shared_zero_copy_between_workloads(monkeypatch):
     """bench.py keeps ONE copy of the SE pool: a workload built with keep_rb_major=False hands out the RB-quad-major tensor that is
     bound (the RB-major tensor the generator wrote is dropped), a second workload binds that very tensor without copying, and both replay the
     same tiles as a workload that kept the RB-major pool."""
     _need_gpu()
+    monkeypatch.delenv("RANENV_SE_LAYOUT", raising=False)        # (the default layout, whatever the suite's pass presets)
     from intent_radio_sched_multi_slice_amd.workloads import make_mult_slice_workload
     dev = torch.device("cuda", 0)
     ref = make_mult_slice_workload(32, dev, n_scenarios=4, n_traces=3, trace_len=7)                      # keeps the RB-major tensor
