@@ -1360,9 +1360,11 @@ DEVFN void persist_loop()
     }
 }
 
-#ifndef RANENV_NARROW_PRIO
-#define RANENV_NARROW_PRIO 1        /* s_setprio of the one-wave class's waves inside the persistent launches (0: none): that class finishes a rollout
-                                       ~7 % behind the two-wave class; issuing first evens them out (gather: K = 20 -2.4 %, K = 200 -0.5 %; streaming: nothing) */
+#ifndef RANENV_CLASS_PRIO
+#define RANENV_CLASS_PRIO 1         /* s_setprio 1 for the waves of the workgroup class that finishes a persistent rollout last (0: none).  Gather mode: the one-wave
+                                       class (K = 20 -2.4 %, round 5); streaming: the two-wave class -- since round 6's trims it ends a 20-TTI rollout ~45 us
+                                       behind the one-wave class (same-box sextuples, K = 20: -1.8 % against priority on the one-wave class, -0.5 % against none;
+                                       the same setting costs gather +1.5 %: profiles/r06_ab_log.txt) */
 #endif
 // waves per SIMD the builds are compiled for: 5 (96 VGPRs) everywhere except the 16-wide row builds of multi-TTI launches (4: they keep
 // 16-entry rows of doubles alive in the allocation and would spill at 96), the small-batch and packed builds (4) and the whole-row builds (2)
@@ -1372,9 +1374,8 @@ __global__ void __launch_bounds__(CORE_NT) __attribute__((amdgpu_waves_per_eu(RA
 {
     (void)p;                                         // (read in place, like step_loop)
 #if RANENV_DIAG == 0 || RANENV_DIAG == 12            /* (the other diagnostic / ablation builds run the launch-per-chunk rollout only) */
-#if RANENV_NARROW_PRIO
-    // the one-wave class finishes a rollout after the two-wave class (its envs have half the loads in flight): its waves issue first
-    if (blockDim.x == WAVE) __builtin_amdgcn_s_setprio(RANENV_NARROW_PRIO);
+#if RANENV_CLASS_PRIO
+    if ((blockDim.x == WAVE) == GATHER) __builtin_amdgcn_s_setprio(RANENV_CLASS_PRIO);
 #endif
     persist_loop<GATHER ? 1 : SE_DEPTH_LEAN, GATHER, NP>();
 #endif
