@@ -1135,7 +1135,11 @@ DEVFN void step_loop(const KP &p)
         for (int k = 0; k < n; k++) {
             kp_const_t kc = (kp_const_t)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kc));
-            if (step_body<MODE_X, NQ, GATHER, NP, false, PACK, MIX>(*kc, cy, warm, MIX ? e_mix : kc->e0 + (int)blockIdx.x * PACK, nullptr, false, false, narrow)) return;
+            // consecutive workgroup ids go round the 8 XCDs (MI355X_MICROARCH.md, Workgroup dispatch): workgroup b = 8 i + k steps the i-th env
+            // of the k-th CONTIGUOUS eighth of the launch's envs, so that an XCD touches one eighth of every per-env array (see persist_try_fresh)
+            const int nb_ = (int)gridDim.x, xk_ = (int)blockIdx.x & 7, q_ = nb_ >> 3, r_ = nb_ & 7;
+            const int b_perm = xk_ * q_ + (xk_ < r_ ? xk_ : r_) + ((int)blockIdx.x >> 3);
+            if (step_body<MODE_X, NQ, GATHER, NP, false, PACK, MIX>(*kc, cy, warm, MIX ? e_mix : kc->e0 + b_perm * PACK, nullptr, false, false, narrow)) return;
             if (k + 1 < n) {
                 // The next TTI takes over in registers what it would otherwise load back (StepCarry): only LDS has to be handed over
                 // between the waves.
@@ -1191,8 +1195,11 @@ template <typename P> DEVFN int persist_try_fresh(const P &p, PersistLocal &pl)
         const int x = (xcc + s8) & 7;
         if (!(pl.fresh_mask >> x & 1)) continue;
         const unsigned j = __hip_atomic_fetch_add(&c->fresh[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long i = (long long)x + 8ll * (long long)j;
-        if (i < (long long)p.p_count) { PSTAT(3); return p.p_list[i]; }  // (TTIs done: 0)
+        // (shard x = a CONTIGUOUS eighth of the class's list, which is in env order: an XCD's workgroups then touch one eighth of every
+        // per-env array -- its L2 and, above all, its address translation see 1/8 of the state's pages instead of all of them; against
+        // the interleaved shards x + 8 j: -1 % per TTI in every schedule, profiles/r06_ab_log.txt)
+        const long long per = ((long long)p.p_count + 7) >> 3, i = (long long)x * per + (long long)j;
+        if ((long long)j < per && i < (long long)p.p_count) { PSTAT(3); return p.p_list[i]; }  // (TTIs done: 0)
         pl.fresh_mask &= ~(1 << x);
     }
     return PERSIST_NONE;
