@@ -1118,11 +1118,23 @@ DEVFN void step_loop(const KP &p)
         if constexpr (MIX) {
             // (the grid is the launch's env count, an upper bound: blocks beyond wide + ceil(narrow / 2) leave at once)
             const int b = (int)blockIdx.x, n_wide = p.m_counts[1], n_narrow = p.m_counts[0];
-            if (b < n_wide) e_mix = p.p_list[b];
-            else {
+            // XCD k = b & 7 steps a contiguous part of each class's list (see step_loop's b_perm below): among the wide blocks the k-th eighth;
+            // among the narrow blocks -- they start at workgroup id n_wide, i.e. at XCD n_wide & 7 -- the blocks of XCD k, counted in XCD order
+            const int k8 = b & 7;
+            if (b < n_wide) {
+                const int q_ = n_wide >> 3, r_ = n_wide & 7;
+                e_mix = p.p_list[k8 * q_ + (k8 < r_ ? k8 : r_) + (b >> 3)];
+            } else {
                 narrow = true;
-                const int idx = 2 * (b - n_wide) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-                if (idx >= n_narrow) return;              // (also: an odd number of narrow envs, the last block's second wave has none)
+                const int nbn = (n_narrow + 1) >> 1, o = n_wide & 7, c = b - n_wide + o;      // c & 7 == k8
+                if (b - n_wide >= nbn) return;
+                // narrow blocks on XCD x: those c in [o, o + nbn) with c & 7 == x
+                auto cnt = [&](int x) { const int hi = o + nbn - 1; return hi < x ? 0 : ((hi - x) >> 3) + 1 - (x < o ? 1 : 0); };
+                int start = 0;
+                for (int x = 0; x < 8; x++) start += x < k8 ? cnt(x) : 0;
+                const int pos = start + (c >> 3) - (k8 < o ? 1 : 0);
+                const int idx = 2 * pos + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                if (idx >= n_narrow) return;
                 e_mix = p.m_list[idx];
             }
         }
