@@ -351,3 +351,44 @@ def test_packed_waves_are_refused_where_a_32_bit_row_offset_could_wrap():
     assert not fits(trf=lim // (25 * 4) + 1) and fits(trf=lim // (25 * 4) - 1)
     assert not fits(tiles=lim // (25 * 8) + 1) and fits(tiles=lim // (25 * 8) - 1)
     assert lib.ranenv_packed_step_fits(None, 0, 0) < 0
+
+
+def test_xcd_aware_env_mapping_is_a_permutation():
+    """The index arithmetic of the XCD-aware env mapping (csrc/ranenv_step_body.hpp: step_loop's b_perm, the mixed launches' wide / narrow
+    positions, persist_try_fresh's contiguous shards), restated: every env of a launch is stepped by exactly one workgroup, and workgroup
+    8 i + k -- XCD k -- gets a contiguous run.  (The kernels themselves are covered by the GPU parity tests: a wrong mapping steps an env
+    twice or not at all.)"""
+    import random
+
+    def plain(nb):                       # step_loop: workgroup b of nb -> position in the launch's env range
+        q, r = nb >> 3, nb & 7
+        return [(b & 7) * q + min(b & 7, r) + (b >> 3) for b in range(nb)]
+
+    def narrow_positions(n_wide, n_narrow):
+        nbn, o = (n_narrow + 1) >> 1, n_wide & 7
+
+        def cnt(x):
+            hi = o + nbn - 1
+            return 0 if hi < x else ((hi - x) >> 3) + 1 - (1 if x < o else 0)
+        out = []
+        for b in range(n_wide, n_wide + nbn):
+            k8, c = b & 7, b - n_wide + o
+            assert c & 7 == k8
+            out.append(sum(cnt(x) for x in range(k8)) + (c >> 3) - (1 if k8 < o else 0))
+        return out, nbn
+
+    def shards(n):                       # persist_try_fresh: shard x = [x * per, min((x + 1) * per, n))
+        per = (n + 7) >> 3
+        return [x * per + j for x in range(8) for j in range(per) if x * per + j < n]
+
+    rng = random.Random(5)
+    cases = [(0, 0), (0, 1), (5, 0), (1023, 3073), (1366, 0), (7, 9), (8, 16)] + [(rng.randint(0, 70), rng.randint(0, 300)) for _ in range(400)]
+    for n_wide, n_narrow in cases:
+        p = plain(n_wide)
+        assert sorted(p) == list(range(n_wide))
+        for k in range(8):               # XCD k's workgroups, in id order, walk a contiguous ascending run
+            run = [p[b] for b in range(k, n_wide, 8)]
+            assert run == list(range(run[0], run[0] + len(run))) if run else True
+        pos, nbn = narrow_positions(n_wide, n_narrow)
+        assert sorted(pos) == list(range(nbn))
+        assert sorted(shards(n_narrow)) == list(range(n_narrow))
