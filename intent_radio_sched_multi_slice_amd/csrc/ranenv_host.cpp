@@ -576,13 +576,12 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
         hipStream_t s = k == 0 ? stream : h->part_stream[(size_t)k];
         if (k > 0 && join_in) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_in, 0));
         KP kc = kp;
-        // (every env of the class has a workgroup of its own and all of them are resident: nobody can ever be waiting, so the
-        // launch is one chunk -- no looks at the queues, no staggered first chunk)
-        // (NOT for the other batches, although at B 4096 the grids equal the class sizes too -- 5119 of 5120 wave slots: two-wave blocks do not
-        // pack perfectly among one-wave blocks, a few dozen workgroups start late, and an env bound to one of those would wait for a whole
+        // (the envs are NOT bound to workgroups statically, although at B 4096 the grids equal the class sizes -- 5119 of 5120 wave slots: two-wave blocks
+        // do not pack perfectly among one-wave blocks, a few dozen workgroups start late, and an env bound to one of those would wait for a whole
         // rollout of somebody else; through the cursors the resident workgroups pick those envs up at their chunk ends.  Measured, round 6:
-        // block i <- list[i] costs +21 % per TTI at K = 20 and +27 % at K = 200 in gather mode, profiles/r06_ab_log.txt)
-        if (tiny && g == n) kc.p_chunk = n_tti > 1 ? n_tti : 1;
+        // block i <- list[i] costs +21 % per TTI at K = 20 and +27 % at K = 200 in gather mode, profiles/r06_ab_log.txt.  Nor is a launch ever ONE chunk,
+        // not even for a batch whose every env has a resident workgroup of its own (configs[1]: round 5 ran those as one chunk): see kp.p_chunk above --
+        // with chunks configs[1] steps 1.2-1.5 % faster at K = 10 / 20)
         kc.p_list = h->d_plist + (size_t)c * B; kc.p_count = n; kc.p_ctl = h->d_pctl + c;
         kc.p_slots = h->d_pslots + (size_t)c * 8 * (size_t)h->p_cap;
         if (h->persist_inject) {                   // test hook: this launch finds a wait already given up
