@@ -427,7 +427,7 @@ int ranenv_autoreset_part(ranenv_handle h, int32_t part, const uint8_t *dev_done
  *                                                 (ranenv_set_partitions cuts an even batch into even ranges); 0: one env per wave
  *   "persist"      RANENV_PERSIST       -1        -1: where it was measured to win (SE gather mode with a batch above 8 workgroups per CU
  *                                                 and up to about twice what the chip holds; either mode with a batch that stays within 2 waves
- *                                                 per SIMD; the streaming kernel at up to 20 envs per CU for rollouts of 6...64 TTIs, where it is 2-9 % ahead -- longer ones are a tie, larger batches lose), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
+ *                                                 per SIMD; the streaming kernel at up to 20 envs per CU for rollouts of 4...64 TTIs, where it is 2-9 % ahead -- longer ones are a tie, larger batches lose), 0: never, 1: wherever possible -- ranenv_rollout runs as ONE persistent launch per workgroup class for all the
  *                                                 TTIs up to the next episode end: the envs are sorted by the waves a compact step
  *                                                 of theirs needs (64 slice members per wave), each class gets a grid of what the
  *                                                 chip holds, and a workgroup that finishes a chunk of TTIs hands its env over

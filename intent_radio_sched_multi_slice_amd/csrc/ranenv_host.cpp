@@ -1373,8 +1373,8 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // Option "persist": one persistent work-queue launch per workgroup class for all the TTIs up to the next episode end
     // (ranenv_persist_kernel), on the caller's stream (+ one handle-owned stream per further class), whatever the partitions.
     // Needs compact steps (the classes are those of the compact lane order) and no head kernel behind every TTI.
-    // (auto, streaming: rollouts of 6...64 TTIs of a batch the chip holds at once -- see below)
-    const bool stream_short = h->se_mode != RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 20ll * h->n_cus && n_steps >= 6 && n_steps <= 64;
+    // (auto, streaming: rollouts of 4...64 TTIs of a batch the chip holds at once -- see below)
+    const bool stream_short = h->se_mode != RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 20ll * h->n_cus && n_steps >= 4 && n_steps <= 64;
     const bool persist_wanted = (RANENV_DIAG == 0 || RANENV_DIAG == 12) && (h->persist == 1 || (h->persist < 0 && ((h->se_mode == RANENV_SE_GATHER && !h->small_batch && (long long)h->cfg.batch <= 44ll * h->n_cus) || persist_tiny(h) || stream_short)));
     // (auto: where it was measured to win or tie -- profiles/r04_ab_log.txt.  Gather mode: B 1024 -4...-6 %, 2048 -1 %, 4096 -6 %, 8192 -2 % per
     // TTI; a batch of several times what the chip holds -- 16 384 one-wave envs at the reference's own size -- swaps at every chunk and
@@ -1385,7 +1385,7 @@ int ranenv_rollout(ranenv_handle h, int32_t n_steps, float *obs_inter, float *ob
     // rollouts of 20 (mean -1.6 %), -5 % for 16, about -1 % for 40...100, a tie at 200 and +9 % for rollouts of 10 (the staggered first chunk is
     // most of such a call); B 8192 loses 7 % (more workgroups than slots: every chunk swaps).  Hence: on for 16...64 TTIs at <= 20 envs per CU.
     // Round 6: what made the short rollouts lose was the chunk, not the schedule -- with a chunk shorter than the launch (persist_launch) rollouts of 6 / 8 / 10 / 12
-    // TTIs are 9 / 9 / 10 / 6 % ahead of the launch-per-chunk rollout (gather mode, always persistent at this size: 12-14 % ahead of itself): on from 6 TTIs.)
+    // TTIs are 9 / 9 / 10 / 6 % ahead of the launch-per-chunk rollout (gather mode, always persistent at this size: 12-14 % ahead of itself); 5 and 4 TTIs: 7 and 4 % ahead, 3 a tie, 2 behind by 16 %: on from 4 TTIs.)
     // (auto: not when episodes end at many different TTIs inside this call -- per-env episode lengths, envs reset at different times:
     // every episode end ends the persistent launches, re-sorts the envs and reads the class counts back; the launch-per-chunk
     // rollout follows the ends per partition without a host sync)

@@ -333,9 +333,9 @@ def test_config2_headline_schedule_vs_oracle(se_mode):
 
     def schedule(k):
         # the auto rule (include/ranenv.h, option persist = -1): the gather mode always runs persistent launches at this size, the
-        # streaming kernel for rollouts of 6...64 TTIs -- the driver's blocks of 20 -- and launch-per-chunk otherwise
+        # streaming kernel for rollouts of 4...64 TTIs -- the driver's blocks of 20 -- and launch-per-chunk otherwise
         if env.get_option("persist") == -1:
-            assert env.get_option("last_rollout_persistent") == (1 if se_mode == "gather" or 6 <= k <= 64 else 0), (se_mode, k)
+            assert env.get_option("last_rollout_persistent") == (1 if se_mode == "gather" or 4 <= k <= 64 else 0), (se_mode, k)
     _mirror_rollouts_with_the_oracle(wl, sample, ROLLOUT_CALLS, se_mode, "configs[2]", after_call=schedule)
     env.close()
 
