@@ -533,7 +533,8 @@ int persist_launch(ranenv_handle h, KP kp, int n_tti, hipStream_t stream)
     const bool gather = h->se_mode == RANENV_SE_GATHER;
     kp.n_tti = n_tti; kp.compact = 1; kp.e0 = 0;
     // (a chunk is always shorter than the launch: an env's FIRST chunk is then 1...chunk TTIs long by a hash of its index, and the envs
-    // reach their chunk ends -- a wait for their stores, a look at the queues -- at different TTIs instead of never.  Measured, round 6: rollouts of
+    // reach their chunk ends -- a wait for their stores, a look at the queues -- at different TTIs instead of never: there they find the env cursors exhausted
+    // and remember it; without a chunk end all workgroups finish together and walk the 8 exhausted cursors with 41 000 device-scope fetch-adds.  Measured, round 6: rollouts of
     // 6 / 8 / 10 TTIs with the default chunk of 10 cost 8-9 % MORE than the launch-per-chunk rollout, with a chunk below the rollout's length
     // 6-7 % LESS, profiles/r06_ab_log.txt)
     kp.p_chunk = h->persist_chunk < n_tti ? h->persist_chunk : (n_tti > 1 ? n_tti - 1 : 1);
